@@ -1,0 +1,241 @@
+"""ORACLE — test infrastructure only.  Not shipped, never on the product path.
+
+Plain-PyTorch fp32 CPU restatement of the reference's RAFT-Stereo inference forward and
+of each hot-path piece, written functionally over a `state_dict` (no nn.Module mirror).
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
+
+Pinned (see tests/test_oracle_golden.py): every function below is checked against golden
+vectors produced by the *imported* reference (`oracle/make_golden.py`, run in the build
+container where /root/reference exists).
+
+Each function cites the reference lines it restates (paths relative to /root/reference).
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+def _conv(sd: SD, name: str, x: torch.Tensor, stride=1, padding=0) -> torch.Tensor:
+    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=padding)
+
+
+def _bn_eval(sd: SD, name: str, x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    # nn.BatchNorm2d in eval mode (scripts call model.eval(): raft_stereo/scripts/inference.py:77)
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
+                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, eps)
+
+
+# ----------------------------------------------------------------------------- encoder
+def residual_block(sd: SD, p: str, x: torch.Tensor, stride: int) -> torch.Tensor:
+    """nndepth/blocks/residual_block.py:53-60 — note the 1x1 `downsample`+norm3 shortcut is
+    ALWAYS applied.  downsample.1 is the same module object as norm3."""
+    y = torch.relu(_bn_eval(sd, p + ".norm1", _conv(sd, p + ".conv1", x, stride=stride, padding=1)))
+    y = torch.relu(_bn_eval(sd, p + ".norm2", _conv(sd, p + ".conv2", y, padding=1)))
+    s = _bn_eval(sd, p + ".norm3", _conv(sd, p + ".downsample.0", x, stride=stride))
+    return torch.relu(s + y)
+
+
+def basic_encoder(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """nndepth/encoders/basic_encoder.py:71-93 (norm_fn='batch', dropout 0)."""
+    x = torch.relu(_bn_eval(sd, p + ".norm1", _conv(sd, p + ".conv1", x, stride=2, padding=3)))
+    for layer, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
+        x = residual_block(sd, f"{p}.{layer}.0", x, stride)
+        x = residual_block(sd, f"{p}.{layer}.1", x, 1)
+    return _conv(sd, p + ".conv2", x)
+
+
+# ------------------------------------------------------------------- correlation volume
+def corr1d_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int) -> List[torch.Tensor]:
+    """nndepth/models/raft_stereo/cost_volume.py:12-34,55-61.
+    Returns num_levels+1 tensors of shape (B*H*W1, 1, W2_l) (the last one is never read: Q1)."""
+    C = fmap1.shape[1]
+    a = fmap1.permute(0, 2, 3, 1)
+    b = fmap2.permute(0, 2, 1, 3)
+    corr = torch.matmul(a, b) / C ** 0.5
+    B, H, W1, W2 = corr.shape
+    corr = corr.reshape(B * H * W1, 1, W2)
+    pyr = [corr]
+    for _ in range(num_levels):
+        corr = F.avg_pool1d(corr, 2)
+        pyr.append(corr)
+    return pyr
+
+
+def linear_sampler(row: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """nndepth/models/raft_stereo/utils.py:4-27 — border clamp (Q2), floor/ceil gather."""
+    w2 = row.shape[1]
+    x = torch.clamp(x / (w2 - 1), 0, 1) * (w2 - 1)
+    i0 = x.floor().long()
+    i1 = x.ceil().long()
+    v0 = row.gather(1, i0)
+    v1 = row.gather(1, i1)
+    coef = i1 - x
+    return coef * v0 + (1 - coef) * v1
+
+
+def corr1d_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, num_levels: int, radius: int) -> torch.Tensor:
+    """nndepth/models/raft_stereo/cost_volume.py:36-53. coords (B,1,H,W) -> (B, L*(2r+1), H, W)."""
+    B, _, H, W = coords.shape
+    outs = []
+    dx = torch.linspace(-radius, radius, 2 * radius + 1).view(1, -1)
+    for i in range(num_levels):
+        row = pyr[i].reshape(B * H * W, -1)
+        x = dx + coords.reshape(B * H * W, 1) / 2 ** i
+        outs.append(linear_sampler(row, x).view(B, H, W, -1))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+# ------------------------------------------------------------------------- update block
+def motion_encoder(sd: SD, p: str, flow: torch.Tensor, corr: torch.Tensor) -> torch.Tensor:
+    """nndepth/blocks/update_block.py:57-65."""
+    cor = torch.relu(_conv(sd, p + ".convc1", corr))
+    cor = torch.relu(_conv(sd, p + ".convc2", cor, padding=1))
+    flo = torch.relu(_conv(sd, p + ".convf1", flow, padding=3))
+    flo = torch.relu(_conv(sd, p + ".convf2", flo, padding=1))
+    out = torch.relu(_conv(sd, p + ".conv", torch.cat([cor, flo], 1), padding=1))
+    return torch.cat([out, flow], 1)
+
+
+def sep_conv_gru(sd: SD, p: str, h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """nndepth/blocks/gru.py:22-37: (1x5) pass then (5x1) pass."""
+    for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
+        hx = torch.cat([h, x], 1)
+        z = torch.sigmoid(_conv(sd, p + ".convz" + sfx, hx, padding=pad))
+        r = torch.sigmoid(_conv(sd, p + ".convr" + sfx, hx, padding=pad))
+        q = torch.tanh(_conv(sd, p + ".convq" + sfx, torch.cat([r * h, x], 1), padding=pad))
+        h = (1 - z) * h + z * q
+    return h
+
+
+def conv_gru(sd: SD, p: str, h: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """nndepth/blocks/gru.py:53-61 (single 3x3)."""
+    hx = torch.cat([h, x], 1)
+    z = torch.sigmoid(_conv(sd, p + ".convz1", hx, padding=1))
+    r = torch.sigmoid(_conv(sd, p + ".convr1", hx, padding=1))
+    q = torch.tanh(_conv(sd, p + ".convq1", torch.cat([r * h, x], 1), padding=1))
+    return (1 - z) * h + z * q
+
+
+def update_block(sd: SD, p: str, net, inp, corr, flow, gru: str = "sep_conv"):
+    """nndepth/blocks/update_block.py:103-112 -> (net, mask, delta_flow)."""
+    mf = motion_encoder(sd, p + ".encoder", flow, corr)
+    x = torch.cat([inp, mf], 1)
+    net = (sep_conv_gru if gru == "sep_conv" else conv_gru)(sd, p + ".gru", net, x)
+    d = _conv(sd, p + ".flow_head.conv2", torch.relu(_conv(sd, p + ".flow_head.conv1", net, padding=1)), padding=1)
+    m = _conv(sd, p + ".mask.2", torch.relu(_conv(sd, p + ".mask.0", net, padding=1)))
+    return net, 0.25 * m, d
+
+
+# ----------------------------------------------------------------------- convex upsample
+def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, rate: int) -> torch.Tensor:
+    """nndepth/models/raft_stereo/model.py:93-105 generalised to C flow channels
+    (cre_stereo/model.py:110-122 is the same with C=2)."""
+    N, C, H, W = flow.shape
+    m = torch.softmax(mask.view(N, 1, 9, rate, rate, H, W), dim=2)
+    u = F.unfold(rate * flow, (3, 3), padding=1).view(N, C, 9, 1, 1, H, W)
+    u = torch.sum(m * u, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return u.reshape(N, C, rate * H, rate * W)
+
+
+# ------------------------------------------------------------------------ full forward
+def raft_stereo_forward(sd: SD, frame1: torch.Tensor, frame2: torch.Tensor, iters: int,
+                        hidden_dim: int = 128, context_dim: int = 64,
+                        corr_levels: int = 4, corr_radius: int = 4,
+                        return_lowres: bool = False):
+    """nndepth/models/raft_stereo/model.py:111-139,160-163 (BaseRAFTStereo).
+    Returns list of up_disp (one per iteration) [and the 1/8-res disparities]."""
+    f = basic_encoder(sd, "fnet", torch.cat([frame1, frame2], 0))
+    fmap1, fmap2 = torch.split(f, f.shape[0] // 2, dim=0)
+    cnet = torch.relu(_conv(sd, "cnet_proj.0", fmap1, padding=1))
+    rate = frame1.shape[-1] // fmap1.shape[-1]
+    fmap1, fmap2 = fmap1.float(), fmap2.float()
+    net, inp = torch.split(cnet, [hidden_dim, context_dim], dim=1)
+    net, inp = torch.tanh(net), torch.relu(inp)
+    pyr = corr1d_build(fmap1, fmap2, corr_levels)
+    B, _, H, W = fmap1.shape
+    org = torch.arange(W).float()[None, None, None, :].repeat(B, 1, H, 1)
+    coords1 = org.clone()
+    ups, lows = [], []
+    for _ in range(iters):
+        samp = corr1d_lookup(pyr, coords1, corr_levels, corr_radius)
+        net, mask, delta = update_block(sd, "update_block", net, inp, samp, coords1 - org)
+        coords1 = coords1 + delta
+        disp = coords1 - org
+        ups.append(convex_upsample(disp, mask, rate))
+        lows.append(disp)
+    return (ups, lows) if return_lowres else ups
+
+
+def epe(disp_gt: torch.Tensor, disp_pred: torch.Tensor, max_flow: float = 1000.0) -> float:
+    """nndepth/models/raft_stereo/scripts/evaluate.py:62-83 for equal-size inputs."""
+    e = torch.sum((disp_pred - disp_gt) ** 2, dim=1).sqrt()
+    mag = torch.sum(disp_gt ** 2, dim=1, keepdim=True).sqrt()
+    valid = mag < max_flow
+    return e.view(-1)[valid.view(-1)].mean().item()
+
+
+def raft_stereo_spec(fnet_dim=256, hidden_dim=128, context_dim=64, corr_levels=4, corr_radius=4,
+                     flow_channel=1, spatial_scale=8) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) list of BaseRAFTStereo.state_dict() — used to generate weights without
+    constructing any module.  Order/keys verified against the imported reference."""
+    spec: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def conv(name, co, ci, kh, kw):
+        spec.append((name + ".weight", (co, ci, kh, kw)))
+        spec.append((name + ".bias", (co,)))
+
+    def bn(name, c):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            spec.append((f"{name}.{s}", (c,)))
+        spec.append((name + ".num_batches_tracked", ()))
+
+    bn("fnet.norm1", 64)
+    conv("fnet.conv1", 64, 3, 7, 7)
+    cin = 64
+    for li, dim in (("layer1", 64), ("layer2", 96), ("layer3", 128)):
+        for bi in (0, 1):
+            p = f"fnet.{li}.{bi}"
+            conv(p + ".conv1", dim, cin, 3, 3)
+            conv(p + ".conv2", dim, dim, 3, 3)
+            bn(p + ".norm1", dim)
+            bn(p + ".norm2", dim)
+            bn(p + ".norm3", dim)
+            conv(p + ".downsample.0", dim, cin, 1, 1)
+            bn(p + ".downsample.1", dim)
+            cin = dim
+    conv("fnet.conv2", fnet_dim, 128, 1, 1)
+    conv("cnet_proj.0", hidden_dim + context_dim, fnet_dim, 3, 3)
+    spec += update_block_spec("update_block", hidden_dim, corr_levels * (2 * corr_radius + 1),
+                              context_dim, flow_channel, spatial_scale)
+    return spec
+
+
+def update_block_spec(p, hidden_dim, cor_planes, context_dim, flow_channel, spatial_scale, gru="sep_conv"):
+    spec = []
+
+    def conv(name, co, ci, kh, kw):
+        spec.append((name + ".weight", (co, ci, kh, kw)))
+        spec.append((name + ".bias", (co,)))
+
+    conv(p + ".encoder.convc1", 256, cor_planes, 1, 1)
+    conv(p + ".encoder.convc2", 192, 256, 3, 3)
+    conv(p + ".encoder.convf1", 128, flow_channel, 7, 7)
+    conv(p + ".encoder.convf2", 64, 128, 3, 3)
+    conv(p + ".encoder.conv", hidden_dim - flow_channel, 256, 3, 3)
+    cin = hidden_dim + context_dim + hidden_dim
+    if gru == "sep_conv":
+        for n in ("convz1", "convr1", "convq1"):
+            conv(f"{p}.gru.{n}", hidden_dim, cin, 1, 5)
+        for n in ("convz2", "convr2", "convq2"):
+            conv(f"{p}.gru.{n}", hidden_dim, cin, 5, 1)
+    else:
+        for n in ("convz1", "convr1", "convq1"):
+            conv(f"{p}.gru.{n}", hidden_dim, cin, 3, 3)
+    conv(p + ".flow_head.conv1", hidden_dim, hidden_dim, 3, 3)
+    conv(p + ".flow_head.conv2", flow_channel, hidden_dim, 3, 3)
+    conv(p + ".mask.0", hidden_dim * 2, hidden_dim, 3, 3)
+    conv(p + ".mask.2", spatial_scale * spatial_scale * 9, hidden_dim * 2, 1, 1)
+    return spec
