@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stereo pairs/s, RAFT-Stereo base, 544x960, 32 GRU iterations, batch 1 per GPU
+(BASELINE.json configs[1]).  One "step" = one full forward() of one stereo pair per rank: encoder
+(PyTorch-ROCm) + HIP correlation pyramid + the fused HIP refinement loop producing all 32 up_disp maps;
+at N > 1 every rank works on its own pair (weak scaling, no collective inside forward) and the step ends
+with the RCCL all-gather of the final disparity.  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  "roofline":     dominant kernel (fp32-MFMA implicit-GEMM conv) measured live with hipEvents on the
+                  launch stream via the C-ABI's nnd_profile_conv, against the 157.3 TFLOP/s fp32 MFMA peak;
+  "cpu_baseline": the oracle's PyTorch-eager CPU restatement of the reference forward timed on the
+                  host cores (rank 0, N=1 only), and the GPU-vs-oracle max-abs of that same pair.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_IMG, W_IMG, ITERS = 544, 960, 32
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from nndepth_amd import parallel, weightgen
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+
+    rank, world, local = parallel.init_distributed("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    # spec of BaseRAFTStereo(context_dim=64) without touching oracle/: keys+shapes from the module itself
+    model = BaseRAFTStereo(iters=ITERS, context_dim=64)
+    weightgen.fill_module_(model)
+    model = model.to(dev).eval()
+    f1, f2 = weightgen.synthetic_frames(100 + rank, 1, H_IMG, W_IMG)  # a different pair per rank
+    f1, f2 = f1.to(dev), f2.to(dev)
+
+    def step():
+        out = model(f1, f2)
+        final = out[-1]["up_disp"]
+        if world > 1:
+            final = parallel.gather_disparity(final)
+        return out, final
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, final = step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+
+    result = {
+        "metric": "stereo pairs/sec at 544x960, 32 iters (RAFT-Stereo)",
+        "value": world * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "RAFT-Stereo base (ctx 64), 544x960, 32 iters, batch 1 per GPU, all 32 up_disp emitted",
+                   "pairs_per_step": world, "parallelism": f"batch-parallel x{world}" if world > 1 else "single"},
+    }
+
+    # ------------------------------------------------------------------ roofline (dominant kernel)
+    if not args.no_roofline and rank == 0:
+        eng = model.update_block.sync_engine(dev)
+        Hf, Wf = H_IMG // 8, W_IMG // 8
+        names = eng.conv_names()
+        rows, tot_ms, tot_fl = [], 0.0, 0.0
+        for i, nm in enumerate(names):
+            ms, fl = eng.profile_conv(i, 1, Hf, Wf, 20, dev)
+            rows.append({"conv": nm, "ms": ms, "gflop": fl / 1e9, "tflops": fl / ms / 1e9})
+            tot_ms += ms
+            tot_fl += fl
+        dom = max(rows, key=lambda r: r["ms"])
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2) — " + dom["conv"],
+            "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": _traffic(),
+            "launch_ms": dom["ms"], "launch_gflop": dom["gflop"],
+            "all_convs": {"ms_per_iter": tot_ms, "gflop_per_iter": tot_fl / 1e9,
+                          "tflops": tot_fl / tot_ms / 1e9, "frac": tot_fl / tot_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS},
+            "per_conv": rows,
+        }
+
+    # ------------------------------------------------------------------ CPU baseline (oracle port)
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import torch_ref as R  # checker / baseline only — never on the product path
+        ncpu = os.cpu_count() or 1
+        torch.set_num_threads(ncpu)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        c1, c2 = f1.cpu(), f2.cpu()
+        with torch.no_grad():
+            ref = R.raft_stereo_forward(sd, c1, c2, ITERS)  # warm-up + parity reference
+            n, t_cpu = 0, 0.0
+            while n < 3 and t_cpu < 30.0:
+                t1 = time.perf_counter()
+                R.raft_stereo_forward(sd, c1, c2, ITERS)
+                t_cpu += time.perf_counter() - t1
+                n += 1
+        result["cpu_baseline"] = {
+            "value": n / t_cpu, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full forwards of the same 544x960 / 32-iter pair (oracle/torch_ref.py, PyTorch CPU eager fp32)",
+        }
+        result["parity_max_abs_vs_oracle"] = float((out[-1]["up_disp"].cpu() - ref[-1]).abs().max())
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def _traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/), else None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("dominant_kernel_hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

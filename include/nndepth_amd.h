@@ -1,0 +1,149 @@
+/*
+ * nndepth_amd — C-ABI of the MI355X (gfx950) stereo-disparity hot path.
+ *
+ * The reference (anhtu293/nndepth) is pure Python/PyTorch and has no FFI layer; its seams
+ * for this path are three duck-typed Python objects on the model instance.
+ * Each entry point below replaces the ATen-op composition behind one of those seams and
+ * cites the reference lines it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all tensors are fp32, NCHW, contiguous, resident in device (HBM) memory unless a
+ *     parameter says "host";
+ *   - the caller owns every buffer including workspaces — the library never allocates or
+ *     frees device memory and never synchronises;
+ *   - all work is enqueued on the caller-supplied hipStream_t (`stream`, may be NULL);
+ *   - return value: 0 on success, negative nnd_status on failure (never throws);
+ *     nnd_last_error() gives a thread-local message for the last failure;
+ *   - no global mutable state besides a read-only device-property cache.
+ */
+#ifndef NNDEPTH_AMD_H
+#define NNDEPTH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NND_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    NND_OK = 0,
+    NND_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    NND_ERR_HIP = -2,         /* a HIP runtime call or launch failed */
+    NND_ERR_UNSUPPORTED = -3, /* configuration not built */
+    NND_ERR_NO_DEVICE = -4
+} nnd_status;
+
+int nnd_version(void);
+const char* nnd_last_error(void);
+/* number of visible HIP devices (0 when none / on a CPU-only host); never raises */
+int nnd_device_count(void);
+
+/* ------------------------------------------------------------------ correlation pyramid
+ * Replaces CorrBlock1D.__init__ + CorrBlock1D.corr
+ *   nndepth/models/raft_stereo/cost_volume.py:12-34,55-61
+ * level 0: corr[b,h,w1,w2] = sum_c f1[b,c,h,w1]*f2[b,c,h,w2] / sqrt(C);
+ * level i+1 = avg_pool1d(level i, 2) (floor on odd widths).  `num_levels`+1 levels are
+ * stored (the reference builds one more than it reads).
+ * Layout of `pyramid`: level l is a dense (B*H*W, W_l) row-major matrix starting at float
+ * offset level_offsets[l] (W_0 = W, W_{l+1} = W_l / 2).                                  */
+int nnd_corr1d_pyramid_layout(int B, int H, int W, int num_levels,
+                              int64_t* level_offsets /* [num_levels+1] */,
+                              int32_t* level_widths /* [num_levels+1] */,
+                              int64_t* total_floats);
+int nnd_corr1d_build(const float* fmap1, const float* fmap2, float* pyramid,
+                     int B, int C, int H, int W, int num_levels, void* stream);
+
+/* Replaces CorrBlock1D.__call__ + linear_sampler
+ *   nndepth/models/raft_stereo/cost_volume.py:36-53, nndepth/models/raft_stereo/utils.py:4-27
+ * coords (B,1,H,W) -> out (B, num_levels*(2*radius+1), H, W); border-clamped (Q2).        */
+int nnd_corr1d_lookup(const float* pyramid, const float* coords, float* out,
+                      int B, int H, int W, int num_levels, int radius, void* stream);
+
+/* ----------------------------------------------------------------------- convex upsample
+ * Replaces RAFTStereo.convex_upsample  nndepth/models/raft_stereo/model.py:93-105
+ * (IGEV copy igev_stereo/model.py:103-115; 2-channel CRE copy cre_stereo/model.py:110-122)
+ * flow (B,C,H,W), mask (B,9*rate*rate,H,W) -> out (B,C,rate*H,rate*W).                    */
+int nnd_convex_upsample(const float* flow, const float* mask, float* out,
+                        int B, int C, int H, int W, int rate, void* stream);
+
+/* -------------------------------------------------------------------------- update block
+ * Replaces BasicUpdateBlock.forward (+BasicMotionEncoder, SepConvGRU/ConvGRU, FlowHead, mask head)
+ *   nndepth/blocks/update_block.py:57-65,26-36,97-112 ; nndepth/blocks/gru.py:22-37,53-61   */
+typedef struct {
+    int32_t hidden_dim;    /* 128 */
+    int32_t context_dim;   /* 64 (YAML) or 128 (class default) */
+    int32_t cor_planes;    /* num_levels*(2r+1) = 36; 576 for IGEV */
+    int32_t flow_channels; /* 1 (RAFT/IGEV) or 2 (CRE) */
+    int32_t mask_channels; /* 9*rate*rate: 576 (/8) or 144 (/4) */
+    int32_t gru_kind;      /* 0 = "sep_conv" (1x5 then 5x1), 1 = "conv_gru" (3x3) */
+} nnd_update_block_desc;
+
+/* Number of weight/bias tensors expected by nnd_update_block_pack, in the order of the
+ * reference module's state_dict(): encoder.{convc1,convc2,convf1,convf2,conv},
+ * gru.{convz1,convr1,convq1[,convz2,convr2,convq2]}, flow_head.{conv1,conv2}, mask.{0,2};
+ * each as (weight, bias).  30 for sep_conv, 24 for conv_gru.                              */
+int nnd_update_block_num_tensors(const nnd_update_block_desc* desc);
+/* size (floats) of the packed parameter blob */
+int64_t nnd_update_block_packed_floats(const nnd_update_block_desc* desc);
+/* HOST function (no GPU needed): re-orders PyTorch-layout (Cout,Cin,KH,KW) fp32 weights into
+ * the MFMA A-fragment order the kernels stream (see DESIGN.md "packed weights").
+ * `tensors_host`: array of host pointers in the order above; `packed_host`: output.       */
+int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const* tensors_host,
+                          float* packed_host);
+/* workspace (floats) needed by nnd_update_block_forward / nnd_raft_stereo_refine          */
+int64_t nnd_update_block_workspace_floats(const nnd_update_block_desc* desc, int B, int H, int W);
+
+/* (net, inp, corr, flow) -> (net_out, mask_out, delta_out); same shapes as the reference:
+ * net (B,hidden,H,W) inp (B,context,H,W) corr (B,cor_planes,H,W) flow (B,fc,H,W)
+ * mask_out (B,mask_channels,H,W) [already x0.25]  delta_out (B,fc,H,W).
+ * mask_out may be NULL (mask head skipped).                                               */
+int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* packed_dev,
+                             const float* net, const float* inp, const float* corr, const float* flow,
+                             float* net_out, float* mask_out, float* delta_out,
+                             float* workspace, int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------- generic convolution
+ * The implicit-GEMM fp32-MFMA convolution the update block is made of, exposed on its own:
+ * stride 1, zero "same" padding (KH/2, KW/2), kernels 1x1, 3x3, 1x5, 5x1.  Stands in for one
+ * nn.Conv2d (+ optional ReLU) call, e.g. nndepth/blocks/update_block.py:58.
+ * nnd_conv2d_pack is a HOST function: w (Cout,Cin,KH,KW), b (Cout) -> packed blob.            */
+int64_t nnd_conv2d_packed_floats(int Cout, int Cin, int KH, int KW);
+int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW,
+                    float* packed_host);
+int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
+                       int Cout, int KH, int KW, int relu, void* stream);
+
+/* ------------------------------------------------------------------ fused refinement loop
+ * Replaces the `for _ in range(self.iters)` loop of RAFTStereo.forward
+ *   nndepth/models/raft_stereo/model.py:126-137 (+ initialize_coords :87-91)
+ * net/inp are the tanh/relu halves of cnet (model.py:119-122); `pyramid` comes from
+ * nnd_corr1d_build.  coords start at arange(W) (+ disp_init if non-NULL).  Every iteration:
+ * lookup -> update block -> coords += delta -> convex upsample of (coords - arange).
+ * up_out: iteration i writes (B,1,rate*H,rate*W) at up_out + i*up_iter_stride floats
+ *         (stride 0 keeps only the last); low_out (optional) receives the final 1/rate-res
+ *         disparity (B,1,H,W); net_out (optional) the final hidden state.
+ * Only flow_channels == 1 (RAFT-Stereo / IGEV-style 1-D disparity).                       */
+int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
+                           const float* pyramid, int num_levels, int radius,
+                           const float* net, const float* inp, const float* disp_init,
+                           float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
+                           float* workspace, int B, int H, int W, int rate, int iters, void* stream);
+
+/* ------------------------------------------------------------------------------ profiling
+ * Times `reps` back-to-back launches of ONE hot-path conv (selected by `which`, see
+ * nnd_conv_name) on `stream` with hipEvents recorded on that same stream and returns the
+ * average milliseconds per launch in *ms_out and its algorithmic FLOPs in *flops_out.
+ * Used by bench.py for the roofline object; inputs are whatever the workspace holds.      */
+int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed_dev, float* workspace,
+                     int B, int H, int W, int which, int reps, void* stream,
+                     float* ms_out, double* flops_out);
+int nnd_num_convs(const nnd_update_block_desc* desc);
+const char* nnd_conv_name(const nnd_update_block_desc* desc, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNDEPTH_AMD_H */

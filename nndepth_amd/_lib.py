@@ -1,0 +1,69 @@
+"""ctypes binding of libnndepth_amd.so (the C-ABI declared in include/nndepth_amd.h).
+
+There is no fallback: if the HIP library is missing the import fails loudly, and every op
+refuses non-CUDA (non-HIP) tensors.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("NND_LIB") or os.path.join(_HERE, "libnndepth_amd.so")
+
+
+class NndError(RuntimeError):
+    pass
+
+
+class UpdateBlockDesc(C.Structure):
+    _fields_ = [("hidden_dim", C.c_int32), ("context_dim", C.c_int32), ("cor_planes", C.c_int32),
+                ("flow_channels", C.c_int32), ("mask_channels", C.c_int32), ("gru_kind", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/nndepth_amd.h one to one
+_P = C.c_void_p
+_I = C.c_int
+SIGNATURES = {
+    "nnd_version": (_I, []),
+    "nnd_last_error": (C.c_char_p, []),
+    "nnd_device_count": (_I, []),
+    "nnd_corr1d_pyramid_layout": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "nnd_corr1d_build": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_corr1d_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_convex_upsample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_update_block_num_tensors": (_I, [C.POINTER(UpdateBlockDesc)]),
+    "nnd_update_block_packed_floats": (C.c_int64, [C.POINTER(UpdateBlockDesc)]),
+    "nnd_update_block_pack": (_I, [C.POINTER(UpdateBlockDesc), C.POINTER(_P), _P]),
+    "nnd_update_block_workspace_floats": (C.c_int64, [C.POINTER(UpdateBlockDesc), _I, _I, _I]),
+    "nnd_update_block_forward": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "nnd_conv2d_packed_floats": (C.c_int64, [_I, _I, _I, _I]),
+    "nnd_conv2d_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "nnd_conv2d_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_raft_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
+                                    _I, _I, _I, _I, _I, _P]),
+    "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
+                              C.POINTER(C.c_double)]),
+    "nnd_num_convs": (_I, [C.POINTER(UpdateBlockDesc)]),
+    "nnd_conv_name": (C.c_char_p, [C.POINTER(UpdateBlockDesc), _I]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise NndError(
+            f"{LIB_PATH} not found: build it with `make -C nndepth_amd/csrc` (or __graft_entry__.build()). "
+            "nndepth_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib.nnd_last_error().decode("utf-8", "replace")
+        raise NndError(f"{what or 'nndepth_amd'} failed (status {rc}): {msg}")

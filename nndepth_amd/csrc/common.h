@@ -1,0 +1,93 @@
+// Internal helpers shared by the HIP translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/nndepth_amd.h"
+
+namespace nnd {
+
+void set_error(const char* fmt, ...);
+
+#define NND_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            nnd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return NND_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define NND_LAUNCH_CHECK()                                                               \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            nnd::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return NND_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define NND_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            nnd::set_error(__VA_ARGS__);                                                 \
+            return NND_ERR_INVALID;                                                      \
+        }                                                                                \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 MFMA (conv_mfma.hip)
+// ---------------------------------------------------------------------------------------
+enum ConvEpilogue {
+    EPI_LINEAR = 0,  // out0 = v
+    EPI_RELU = 1,    // out0 = max(v, 0)
+    EPI_GRU_ZR = 2,  // co <  hidden: out0[co] = sigmoid(v)                (z)
+                     // co >= hidden: out1[co-hidden] = sigmoid(v) * aux0  (r*h)
+    EPI_GRU_Q = 3,   // q = tanh(v); out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z)
+    EPI_SCALE = 4    // out0 = scale * v
+};
+
+// One convolution layer inside a packed parameter blob.
+struct ConvLayer {
+    int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (8 or 32)
+    int nchunks;                  // ceil(Cin / CI_T)
+    int ncb;                      // ceil(Cout / 32) output-channel blocks
+    int64_t w_off, b_off;         // float offsets in the blob
+    int64_t w_floats() const { return (int64_t)ncb * nchunks * KH * KW * CI_T * 32; }
+    int64_t b_floats() const { return (int64_t)ncb * 32; }
+    double flops(int B, int H, int W) const { return 2.0 * B * H * W * (double)Cout * Cin * KH * KW; }
+};
+
+// A source / destination activation: channel-slice of an NCHW tensor (channel stride = H*W).
+struct Act {
+    float* ptr;     // first channel of the slice, batch 0
+    int64_t bstride;  // floats between batches
+    int C;          // channels in the slice
+};
+
+struct ConvIO {
+    Act src0, src1;      // virtual concat [src0, src1] along channels (src1.C may be 0)
+    Act out0, out1;      // see ConvEpilogue
+    Act aux0, aux1;
+    int hidden = 0;
+    float scale = 1.f;
+};
+
+int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi,
+                int B, int H, int W, hipStream_t stream);
+
+// Host-side packing of one (virtually concatenated along Cout) conv into A-fragment order.
+// w[i]: (cout[i], Cin, KH, KW) row-major, b[i]: (cout[i]).
+void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const float* const* b,
+               const int* cout, float* blob);
+
+// corr1d.hip
+int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,
+                         int radius, hipStream_t stream);
+int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
+                           hipStream_t stream);
+
+}  // namespace nnd

@@ -1,0 +1,506 @@
+// RAFT update operator (motion encoder -> SepConvGRU / ConvGRU -> flow head + mask head) and the
+// fused per-pair refinement loop, as a fixed sequence of launches of the fp32-MFMA implicit-GEMM
+// convolution (conv_mfma.hip) plus three small VALU kernels.
+//
+// Replaces nndepth/blocks/update_block.py:57-65 (BasicMotionEncoder), :26-36 (FlowHead), :97-112
+// (BasicUpdateBlock.forward + mask head), nndepth/blocks/gru.py:22-37 (SepConvGRU), :53-61 (ConvGRU) and
+// the loop of nndepth/models/raft_stereo/model.py:126-137 (reference; restated in oracle/torch_ref.py).
+//
+// torch.cat is never materialised: tensors that the reference concatenates live side by side in one
+// workspace buffer (hx = [h | inp | motion | flow], cf = [cor | flo], fm = [flow_head.conv1 | mask.0]) and the
+// convolutions write straight into their channel slice.  convz/convr are packed as one 2*hidden-channel
+// conv whose epilogue emits z and r*h; convq's epilogue does the GRU blend in place; flow_head.conv1 and
+// mask.0 (same input) are packed as one 3*hidden-channel conv.
+#include "common.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace nnd {
+
+// ------------------------------------------------------------------------------------ plan
+enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1, C_Q1, C_ZR2, C_Q2, C_FM1, C_FC2, C_M2, C_COUNT };
+static const char* kConvNames[C_COUNT] = {"encoder.convc1",        "encoder.convc2", "encoder.convf2", "encoder.conv",
+                                          "gru.convz1+convr1",     "gru.convq1",     "gru.convz2+convr2", "gru.convq2",
+                                          "flow_head.conv1+mask.0", "flow_head.conv2", "mask.2"};
+
+struct Plan {
+    nnd_update_block_desc d;
+    bool sep;
+    ConvLayer L[C_COUNT];
+    int64_t f1_w, f1_b;  // raw encoder.convf1 weights [128][fc][49] + bias [128]
+    int64_t total;
+};
+
+static ConvLayer mk(int KH, int KW, int Cin, int Cout, int CI_T, int64_t* off) {
+    ConvLayer l;
+    l.KH = KH; l.KW = KW; l.Cin = Cin; l.Cout = Cout; l.CI_T = CI_T;
+    l.nchunks = cdiv(Cin, CI_T);
+    l.ncb = cdiv(Cout, 32);
+    l.w_off = *off;
+    *off += l.w_floats();
+    l.b_off = *off;
+    *off += l.b_floats();
+    return l;
+}
+
+static int make_plan(const nnd_update_block_desc* d, Plan* p) {
+    NND_REQUIRE(d, "update_block: null descriptor");
+    const int hid = d->hidden_dim, ctx = d->context_dim, cp = d->cor_planes, fc = d->flow_channels, mc = d->mask_channels;
+    NND_REQUIRE(hid > 0 && hid % 32 == 0, "update_block: hidden_dim %d must be a positive multiple of 32", hid);
+    NND_REQUIRE(ctx > 0 && ctx % 8 == 0, "update_block: context_dim %d must be a positive multiple of 8", ctx);
+    NND_REQUIRE(cp > 0 && (fc == 1 || fc == 2) && mc > 0 && mc % 9 == 0, "update_block: bad cor_planes/flow_channels/mask_channels");
+    NND_REQUIRE(d->gru_kind == 0 || d->gru_kind == 1, "update_block: gru_kind must be 0 (sep_conv) or 1 (conv_gru)");
+    p->d = *d;
+    p->sep = d->gru_kind == 0;
+    int64_t off = 0;
+    const int gin = hid + ctx + hid;
+    p->L[C_C1] = mk(1, 1, cp, 256, cp >= 64 ? 32 : 8, &off);
+    p->L[C_C2] = mk(3, 3, 256, 192, 8, &off);
+    p->f1_w = off; off += (int64_t)128 * fc * 49;
+    p->f1_b = off; off += 128;
+    p->L[C_F2] = mk(3, 3, 128, 64, 8, &off);
+    p->L[C_CV] = mk(3, 3, 256, hid - fc, 8, &off);
+    if (p->sep) {
+        p->L[C_ZR1] = mk(1, 5, gin, 2 * hid, 8, &off);
+        p->L[C_Q1] = mk(1, 5, gin, hid, 8, &off);
+        p->L[C_ZR2] = mk(5, 1, gin, 2 * hid, 8, &off);
+        p->L[C_Q2] = mk(5, 1, gin, hid, 8, &off);
+    } else {
+        p->L[C_ZR1] = mk(3, 3, gin, 2 * hid, 8, &off);
+        p->L[C_Q1] = mk(3, 3, gin, hid, 8, &off);
+        p->L[C_ZR2] = p->L[C_ZR1];
+        p->L[C_Q2] = p->L[C_Q1];
+    }
+    p->L[C_FM1] = mk(3, 3, hid, 3 * hid, 8, &off);
+    p->L[C_FC2] = mk(3, 3, hid, fc, 8, &off);
+    p->L[C_M2] = mk(1, 1, 2 * hid, mc, 32, &off);
+    p->total = off;
+    return NND_OK;
+}
+
+// ------------------------------------------------------------------------------- workspace
+struct Bufs {
+    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow;
+    int64_t total;
+};
+
+static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
+    const int64_t n = (int64_t)B * H * W;
+    const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels;
+    int64_t off = 0;
+    auto take = [&](int C) {
+        float* ptr = base ? base + off : nullptr;
+        off += ((int64_t)C * n + 63) / 64 * 64;  // keep every buffer 256-B aligned
+        return ptr;
+    };
+    b->c1 = take(256);
+    b->cf = take(256);
+    b->f1 = take(128);
+    b->hx = take(2 * hid + ctx);
+    b->z = take(hid);
+    b->rh = take(hid);
+    b->fm = take(3 * hid);
+    b->corr = take(p.d.cor_planes);
+    b->mask = take(p.d.mask_channels);
+    b->delta = take(fc);
+    b->coords = take(1);
+    b->flow = take(fc);
+    b->total = off;
+}
+
+// ------------------------------------------------------------------------- small kernels
+// encoder.convf1: 7x7, Cin = FC (1 or 2) -> 128, ReLU.  K = 49*FC is too shallow for the MFMA path;
+// each thread keeps its 49*FC-tap neighbourhood in registers and the (wave-uniform) weights come in
+// through the scalar cache.  grid (tiles of 8x32 px, 128/32 channel groups, B), 256 threads.
+template <int FC>
+__global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ flow, long fbs, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, long obs,
+                                                     int H, int W, int tiles_x) {
+    __shared__ float patch[FC][14][40];
+    const int tid = threadIdx.x;
+    const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
+    const int b = blockIdx.z, co0 = blockIdx.y * 32;
+    const long HW = (long)H * W;
+    for (int e = tid; e < FC * 14 * 38; e += 256) {
+        int c = e / (14 * 38), rem = e % (14 * 38);
+        int pr = rem / 38, pc = rem % 38;
+        int gy = ty0 + pr - 3, gx = tx0 + pc - 3;
+        patch[c][pr][pc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? flow[b * fbs + c * HW + (long)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    const int ty = tid >> 5, tx = tid & 31;
+    float v[FC * 49];
+#pragma unroll
+    for (int c = 0; c < FC; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) v[c * 49 + dy * 7 + dx] = patch[c][ty + dy][tx + dx];
+    const int y = ty0 + ty, x = tx0 + tx;
+    const bool ok = y < H && x < W;
+    for (int co = co0; co < co0 + 32; ++co) {
+        const float* wc = w + (long)co * (FC * 49);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < FC * 49; ++i) acc = fmaf(wc[i], v[i], acc);
+        acc += bias[co];
+        if (ok) out[b * obs + co * HW + (long)y * W + x] = fmaxf(acc, 0.f);
+    }
+}
+
+// coords += delta; flow = coords - x  (model.py:134-135), mirrored into the GRU input buffer.
+__global__ void advance_kernel(float* __restrict__ coords, const float* __restrict__ delta, float* __restrict__ flow,
+                               float* __restrict__ hx_flow, long hx_bs, int B, int H, int W) {
+    const long HW = (long)H * W;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = (int)(idx / HW);
+    const long pix = idx % HW;
+    const int x = (int)(pix % W);
+    float cnew = coords[idx] + delta[idx];
+    float f = cnew - (float)x;
+    coords[idx] = cnew;
+    flow[idx] = f;
+    hx_flow[b * hx_bs + pix] = f;
+}
+
+// coords = x (+ disp_init); flow = coords - x
+__global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict__ flow, float* __restrict__ hx_flow,
+                                   long hx_bs, const float* __restrict__ disp_init, int B, int H, int W) {
+    const long HW = (long)H * W;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const int b = (int)(idx / HW);
+    const long pix = idx % HW;
+    const int x = (int)(pix % W);
+    float c = (float)x + (disp_init ? disp_init[idx] : 0.f);
+    float f = c - (float)x;
+    coords[idx] = c;
+    flow[idx] = f;
+    hx_flow[b * hx_bs + pix] = f;
+}
+
+// ------------------------------------------------------------------------------ sequencing
+static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
+
+// IO of conv `id` given the workspace; `corr` / `flow_src` are the external inputs.
+static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*H*W*/, float* mask_dst, float* delta_dst) {
+    const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels;
+    const int hxC = 2 * hid + ctx;
+    ConvIO io{};
+    switch (id) {
+        case C_C1: io.src0 = corr; io.out0 = act(w.c1, 256 * n, 256); break;
+        case C_C2: io.src0 = act(w.c1, 256 * n, 256); io.out0 = act(w.cf, 256 * n, 192); break;
+        case C_F2: io.src0 = act(w.f1, 128 * n, 128); io.out0 = act(w.cf + 192 * n, 256 * n, 64); break;
+        case C_CV: io.src0 = act(w.cf, 256 * n, 256); io.out0 = act(w.hx + (hid + ctx) * n, hxC * n, hid - fc); break;
+        case C_ZR1:
+        case C_ZR2:
+            io.src0 = act(w.hx, hxC * n, hxC);
+            io.out0 = act(w.z, hid * n, hid);
+            io.out1 = act(w.rh, hid * n, hid);
+            io.aux0 = act(w.hx, hxC * n, hid);
+            io.hidden = hid;
+            break;
+        case C_Q1:
+        case C_Q2:
+            io.src0 = act(w.rh, hid * n, hid);
+            io.src1 = act(w.hx + hid * n, hxC * n, ctx + hid);
+            io.out0 = act(w.hx, hxC * n, hid);
+            io.aux0 = act(w.hx, hxC * n, hid);
+            io.aux1 = act(w.z, hid * n, hid);
+            break;
+        case C_FM1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, 3 * hid); break;
+        case C_FC2: io.src0 = act(w.fm, 3 * hid * n, hid); io.out0 = act(delta_dst, fc * n, fc); break;
+        case C_M2:
+            io.src0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
+            io.out0 = act(mask_dst, p.d.mask_channels * n, p.d.mask_channels);
+            io.scale = 0.25f;
+            break;
+    }
+    return io;
+}
+
+static int conv_epi(int id) {
+    switch (id) {
+        case C_ZR1: case C_ZR2: return EPI_GRU_ZR;
+        case C_Q1: case C_Q2: return EPI_GRU_Q;
+        case C_FC2: return EPI_LINEAR;
+        case C_M2: return EPI_SCALE;
+        default: return EPI_RELU;
+    }
+}
+
+// NND_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault localisation only).
+static int debug_sync(const char* what, hipStream_t s) {
+    static const bool on = getenv("NND_DEBUG_SYNC") != nullptr;
+    if (!on) return NND_OK;
+    fprintf(stderr, "[nnd] %s ...", what);
+    fflush(stderr);
+    NND_HIP_CHECK(hipStreamSynchronize(s));
+    fprintf(stderr, " ok\n");
+    fflush(stderr);
+    return NND_OK;
+}
+
+static int run_conv(const Plan& p, const float* blob, const Bufs& w, int id, Act corr, float* mask_dst, float* delta_dst,
+                    int B, int H, int W, hipStream_t s) {
+    ConvIO io = conv_io(p, w, id, corr, (int64_t)H * W, mask_dst, delta_dst);
+    int rc = launch_conv(p.L[id], blob, io, conv_epi(id), B, H, W, s);
+    if (rc != NND_OK) return rc;
+    return debug_sync(kConvNames[id], s);
+}
+
+static int run_convf1(const Plan& p, const float* blob, const float* flow, int64_t fbs, float* out, int B, int H, int W,
+                      hipStream_t s) {
+    const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8);
+    dim3 grid(tiles_x * tiles_y, 4, B), block(256);
+    const int64_t n = (int64_t)H * W;
+    if (p.d.flow_channels == 1)
+        hipLaunchKernelGGL(convf1_kernel<1>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x);
+    else
+        hipLaunchKernelGGL(convf1_kernel<2>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x);
+    NND_LAUNCH_CHECK();
+    return debug_sync("encoder.convf1", s);
+}
+
+// One application of the update block on workspace state: expects h/inp/flow already in w.hx,
+// `flow` = (B,fc,H,W) dense.  Writes new h into w.hx[0:hid], delta, and (optionally) the mask.
+static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr, const float* flow, float* mask_dst,
+                      float* delta_dst, int B, int H, int W, hipStream_t s) {
+    int rc;
+#define NND_TRY(x) if ((rc = (x)) != NND_OK) return rc
+    NND_TRY(run_conv(p, blob, w, C_C1, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_C2, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_convf1(p, blob, flow, (int64_t)p.d.flow_channels * H * W, w.f1, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_F2, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_CV, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_ZR1, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_Q1, corr, nullptr, nullptr, B, H, W, s));
+    if (p.sep) {
+        NND_TRY(run_conv(p, blob, w, C_ZR2, corr, nullptr, nullptr, B, H, W, s));
+        NND_TRY(run_conv(p, blob, w, C_Q2, corr, nullptr, nullptr, B, H, W, s));
+    }
+    NND_TRY(run_conv(p, blob, w, C_FM1, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_FC2, corr, nullptr, delta_dst, B, H, W, s));
+    if (mask_dst) NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
+    return NND_OK;
+}
+
+static int copy_slice(float* dst, int64_t dbs, const float* src, int64_t sbs, int64_t floats, int B, hipStream_t s) {
+    NND_HIP_CHECK(hipMemcpy2DAsync(dst, dbs * sizeof(float), src, sbs * sizeof(float), floats * sizeof(float), B,
+                                   hipMemcpyDeviceToDevice, s));
+    return NND_OK;
+}
+
+}  // namespace nnd
+
+using namespace nnd;
+
+extern "C" {
+
+int nnd_update_block_num_tensors(const nnd_update_block_desc* desc) {
+    Plan p;
+    if (make_plan(desc, &p) != NND_OK) return NND_ERR_INVALID;
+    return p.sep ? 30 : 24;
+}
+
+int64_t nnd_update_block_packed_floats(const nnd_update_block_desc* desc) {
+    Plan p;
+    if (make_plan(desc, &p) != NND_OK) return NND_ERR_INVALID;
+    return p.total;
+}
+
+int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const* t, float* out) {
+    Plan p;
+    int rc = make_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(t && out, "update_block_pack: null pointer");
+    const int n = p.sep ? 30 : 24;
+    for (int i = 0; i < n; ++i) NND_REQUIRE(t[i], "update_block_pack: tensor %d is null", i);
+    const int hid = p.d.hidden_dim, fc = p.d.flow_channels;
+    memset(out, 0, sizeof(float) * p.total);
+    auto one = [&](int id, int ti) {
+        const float* w[1] = {t[ti]};
+        const float* b[1] = {t[ti + 1]};
+        int co[1] = {p.L[id].Cout};
+        pack_conv(p.L[id], 1, w, b, co, out);
+    };
+    auto two = [&](int id, int ta, int tb, int ca, int cb) {
+        const float* w[2] = {t[ta], t[tb]};
+        const float* b[2] = {t[ta + 1], t[tb + 1]};
+        int co[2] = {ca, cb};
+        pack_conv(p.L[id], 2, w, b, co, out);
+    };
+    one(C_C1, 0);
+    one(C_C2, 2);
+    memcpy(out + p.f1_w, t[4], sizeof(float) * 128 * fc * 49);
+    memcpy(out + p.f1_b, t[5], sizeof(float) * 128);
+    one(C_F2, 6);
+    one(C_CV, 8);
+    two(C_ZR1, 10, 12, hid, hid);
+    one(C_Q1, 14);
+    int k = 16;
+    if (p.sep) {
+        two(C_ZR2, 16, 18, hid, hid);
+        one(C_Q2, 20);
+        k = 22;
+    }
+    two(C_FM1, k, k + 4, hid, 2 * hid);  // flow_head.conv1 | mask.0
+    one(C_FC2, k + 2);
+    one(C_M2, k + 6);
+    return NND_OK;
+}
+
+int64_t nnd_update_block_workspace_floats(const nnd_update_block_desc* desc, int B, int H, int W) {
+    Plan p;
+    if (make_plan(desc, &p) != NND_OK || B <= 0 || H <= 0 || W <= 0) return NND_ERR_INVALID;
+    Bufs b;
+    carve(p, B, H, W, nullptr, &b);
+    return b.total;
+}
+
+int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* packed, const float* net, const float* inp,
+                             const float* corr, const float* flow, float* net_out, float* mask_out, float* delta_out,
+                             float* workspace, int B, int H, int W, void* stream) {
+    Plan p;
+    int rc = make_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed && net && inp && corr && flow && net_out && delta_out && workspace, "update_block_forward: null pointer");
+    NND_REQUIRE(B > 0 && H > 0 && W > 0, "update_block_forward: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    Bufs w;
+    carve(p, B, H, W, workspace, &w);
+    const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels, hxC = 2 * hid + ctx;
+    const int64_t n = (int64_t)H * W;
+    NND_TRY(copy_slice(w.hx, hxC * n, net, hid * n, hid * n, B, s));
+    NND_TRY(copy_slice(w.hx + hid * n, hxC * n, inp, ctx * n, ctx * n, B, s));
+    NND_TRY(copy_slice(w.hx + (hxC - fc) * n, hxC * n, flow, fc * n, fc * n, B, s));
+    Act c = act(const_cast<float*>(corr), p.d.cor_planes * n, p.d.cor_planes);
+    NND_TRY(run_update(p, packed, w, c, flow, mask_out, delta_out, B, H, W, s));
+    NND_TRY(copy_slice(net_out, hid * n, w.hx, hxC * n, hid * n, B, s));
+    return NND_OK;
+}
+
+int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
+                           int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
+                           int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W,
+                           int rate, int iters, void* stream) {
+    Plan p;
+    int rc = make_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed && pyramid && net && inp && up_out && workspace, "raft_stereo_refine: null pointer");
+    NND_REQUIRE(p.d.flow_channels == 1, "raft_stereo_refine: flow_channels must be 1");
+    NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1), "raft_stereo_refine: cor_planes %d != levels*(2r+1)", p.d.cor_planes);
+    NND_REQUIRE(p.d.mask_channels == 9 * rate * rate, "raft_stereo_refine: mask_channels %d != 9*rate^2", p.d.mask_channels);
+    NND_REQUIRE(B > 0 && H > 0 && W > 0 && iters > 0, "raft_stereo_refine: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    Bufs w;
+    carve(p, B, H, W, workspace, &w);
+    const int hid = p.d.hidden_dim, ctx = p.d.context_dim, hxC = 2 * hid + ctx;
+    const int64_t n = (int64_t)H * W;
+    NND_TRY(copy_slice(w.hx, hxC * n, net, hid * n, hid * n, B, s));
+    NND_TRY(copy_slice(w.hx + hid * n, hxC * n, inp, ctx * n, ctx * n, B, s));
+    float* hx_flow = w.hx + (hxC - 1) * n;
+    const unsigned eg = (unsigned)cdiv64((int64_t)B * n, 256);
+    hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H, W);
+    NND_LAUNCH_CHECK();
+    Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
+    for (int it = 0; it < iters; ++it) {
+        NND_TRY(corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, s));
+        NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
+        hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W);
+        NND_LAUNCH_CHECK();
+        NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s));
+    }
+    if (low_out) NND_TRY(copy_slice(low_out, n, w.flow, n, n, B, s));
+    if (net_out) NND_TRY(copy_slice(net_out, hid * n, w.hx, hxC * n, hid * n, B, s));
+    return NND_OK;
+}
+
+static int conv2d_layer(int Cout, int Cin, int KH, int KW, ConvLayer* L, int64_t* total) {
+    NND_REQUIRE(Cout > 0 && Cin > 0, "conv2d: bad channel counts");
+    NND_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 1 && KW == 5) || (KH == 5 && KW == 1),
+                "conv2d: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", KH, KW);
+    int64_t off = 0;
+    *L = mk(KH, KW, Cin, Cout, (KH == 1 && KW == 1 && Cin >= 64) ? 32 : 8, &off);
+    if (total) *total = off;
+    return NND_OK;
+}
+
+int64_t nnd_conv2d_packed_floats(int Cout, int Cin, int KH, int KW) {
+    ConvLayer L;
+    int64_t total;
+    if (conv2d_layer(Cout, Cin, KH, KW, &L, &total) != NND_OK) return NND_ERR_INVALID;
+    return total;
+}
+
+int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW, float* packed_host) {
+    ConvLayer L;
+    int rc = conv2d_layer(Cout, Cin, KH, KW, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(w_host && b_host && packed_host, "conv2d_pack: null pointer");
+    const float* w[1] = {w_host};
+    const float* b[1] = {b_host};
+    int co[1] = {Cout};
+    pack_conv(L, 1, w, b, co, packed_host);
+    return NND_OK;
+}
+
+int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
+                       int KW, int relu, void* stream) {
+    ConvLayer L;
+    int rc = conv2d_layer(Cout, Cin, KH, KW, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev && x && y && B > 0 && H > 0 && W > 0, "conv2d_forward: bad argument");
+    const int64_t n = (int64_t)H * W;
+    ConvIO io{};
+    io.src0 = act(const_cast<float*>(x), Cin * n, Cin);
+    io.out0 = act(y, Cout * n, Cout);
+    return launch_conv(L, packed_dev, io, relu ? EPI_RELU : EPI_LINEAR, B, H, W, (hipStream_t)stream);
+}
+
+int nnd_num_convs(const nnd_update_block_desc* desc) {
+    Plan p;
+    if (make_plan(desc, &p) != NND_OK) return NND_ERR_INVALID;
+    return C_COUNT;
+}
+
+const char* nnd_conv_name(const nnd_update_block_desc* desc, int which) {
+    (void)desc;
+    return (which >= 0 && which < C_COUNT) ? kConvNames[which] : "";
+}
+
+int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, float* workspace, int B, int H, int W, int which,
+                     int reps, void* stream, float* ms_out, double* flops_out) {
+    Plan p;
+    int rc = make_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed && workspace && ms_out && flops_out, "profile_conv: null pointer");
+    NND_REQUIRE(which >= 0 && which < C_COUNT && reps > 0, "profile_conv: bad conv index / reps");
+    NND_REQUIRE(p.sep || (which != C_ZR2 && which != C_Q2), "profile_conv: conv_gru has no second GRU pass");
+    hipStream_t s = (hipStream_t)stream;
+    Bufs w;
+    carve(p, B, H, W, workspace, &w);
+    const int64_t n = (int64_t)H * W;
+    Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
+    hipEvent_t e0, e1;
+    NND_HIP_CHECK(hipEventCreate(&e0));
+    NND_HIP_CHECK(hipEventCreate(&e1));
+    rc = run_conv(p, packed, w, which, c, w.mask, w.delta, B, H, W, s);  // warm
+    if (rc == NND_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < reps && rc == NND_OK; ++i) rc = run_conv(p, packed, w, which, c, w.mask, w.delta, B, H, W, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_out = ms / reps;
+        *flops_out = p.L[which].flops(B, H, W);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+}

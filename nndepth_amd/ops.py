@@ -1,0 +1,227 @@
+"""Tensor-level wrappers over the C-ABI (include/nndepth_amd.h).
+
+PyTorch is plumbing only: it owns device memory and the HIP stream; every computation is a
+call into libnndepth_amd.so.  All ops require fp32 tensors on a HIP ("cuda") device and
+raise otherwise — there is no CPU or eager fallback.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import NndError, UpdateBlockDesc, check, lib
+
+
+def _dev(*tensors: torch.Tensor) -> torch.device:
+    d = tensors[0].device
+    for t in tensors:
+        if t.device.type != "cuda":
+            raise NndError("nndepth_amd ops run on the HIP device only; got a tensor on "
+                           f"{t.device} (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise NndError(f"nndepth_amd ops are fp32; got {t.dtype}")
+        if t.device != d:
+            raise NndError("all tensors must live on the same device")
+    return d
+
+
+def _stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ---------------------------------------------------------------------------- correlation
+def pyramid_layout(B: int, H: int, W: int, num_levels: int) -> Tuple[List[int], List[int], int]:
+    offs = (C.c_int64 * (num_levels + 1))()
+    wid = (C.c_int32 * (num_levels + 1))()
+    tot = C.c_int64()
+    check(lib.nnd_corr1d_pyramid_layout(B, H, W, num_levels, offs, wid, C.byref(tot)), "corr1d_pyramid_layout")
+    return list(offs), list(wid), tot.value
+
+
+def corr1d_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int) -> torch.Tensor:
+    """-> flat fp32 pyramid buffer (see pyramid_layout)."""
+    d = _dev(fmap1, fmap2)
+    if fmap1.shape != fmap2.shape or fmap1.dim() != 4:
+        raise NndError(f"corr1d_build: fmap shapes {tuple(fmap1.shape)} vs {tuple(fmap2.shape)}")
+    fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+    B, Cc, H, W = fmap1.shape
+    _, _, total = pyramid_layout(B, H, W, num_levels)
+    pyr = torch.empty(total, dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_corr1d_build(_p(fmap1), _p(fmap2), _p(pyr), B, Cc, H, W, num_levels, _stream(d)), "corr1d_build")
+    return pyr
+
+
+def corr1d_lookup(pyr: torch.Tensor, coords: torch.Tensor, num_levels: int, radius: int) -> torch.Tensor:
+    d = _dev(pyr, coords)
+    coords = coords.contiguous()
+    B, one, H, W = coords.shape
+    if one != 1:
+        raise NndError("corr1d_lookup: coords must be (B,1,H,W)")
+    out = torch.empty((B, num_levels * (2 * radius + 1), H, W), dtype=torch.float32, device=d)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(d):
+        check(lib.nnd_corr1d_lookup(_p(pyr), _p(coords), _p(out), B, H, W, num_levels, radius, _stream(d)), "corr1d_lookup")
+    return out
+
+
+def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, rate: int) -> torch.Tensor:
+    d = _dev(flow, mask)
+    flow, mask = flow.contiguous(), mask.contiguous()
+    B, Cf, H, W = flow.shape
+    if tuple(mask.shape) != (B, 9 * rate * rate, H, W):
+        raise NndError(f"convex_upsample: mask shape {tuple(mask.shape)} != {(B, 9 * rate * rate, H, W)}")
+    out = torch.empty((B, Cf, rate * H, rate * W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_convex_upsample(_p(flow), _p(mask), _p(out), B, Cf, H, W, rate, _stream(d)), "convex_upsample")
+    return out
+
+
+# ------------------------------------------------------------------------ generic conv2d
+class Conv2d:
+    """One packed stride-1 "same" convolution (1x1, 3x3, 1x5, 5x1) on the fp32-MFMA kernel."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, device="cuda"):
+        self.Cout, self.Cin, self.KH, self.KW = (int(s) for s in weight.shape)
+        n = int(lib.nnd_conv2d_packed_floats(self.Cout, self.Cin, self.KH, self.KW))
+        if n <= 0:
+            check(n, "conv2d_packed_floats")
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        b = bias.detach().to("cpu", torch.float32).contiguous()
+        blob = torch.empty(n, dtype=torch.float32)
+        check(lib.nnd_conv2d_pack(_p(w), _p(b), self.Cout, self.Cin, self.KH, self.KW, _p(blob)), "conv2d_pack")
+        self.packed_host = blob
+        self.packed = blob.to(device) if device is not None else None
+
+    def __call__(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        d = _dev(x, self.packed)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        if Cin != self.Cin:
+            raise NndError(f"conv2d: input has {Cin} channels, weights expect {self.Cin}")
+        y = torch.empty((B, self.Cout, H, W), dtype=torch.float32, device=d)
+        with torch.cuda.device(d):
+            check(lib.nnd_conv2d_forward(_p(self.packed), _p(x), _p(y), B, Cin, H, W, self.Cout, self.KH, self.KW,
+                                         int(relu), _stream(d)), "conv2d_forward")
+        return y
+
+
+# --------------------------------------------------------------------------- update block
+# order of the reference module's state_dict (nndepth/blocks/update_block.py:39-55,68-101)
+def update_block_keys(gru: str = "sep_conv") -> List[str]:
+    names = ["encoder.convc1", "encoder.convc2", "encoder.convf1", "encoder.convf2", "encoder.conv",
+             "gru.convz1", "gru.convr1", "gru.convq1"]
+    if gru == "sep_conv":
+        names += ["gru.convz2", "gru.convr2", "gru.convq2"]
+    names += ["flow_head.conv1", "flow_head.conv2", "mask.0", "mask.2"]
+    return [f"{n}.{s}" for n in names for s in ("weight", "bias")]
+
+
+class UpdateBlockEngine:
+    """Packed parameters + workspace for one BasicUpdateBlock configuration."""
+
+    def __init__(self, hidden_dim: int, context_dim: int, cor_planes: int, flow_channels: int,
+                 mask_channels: int, gru: str = "sep_conv"):
+        if gru not in ("sep_conv", "conv_gru"):
+            raise NndError(f"unknown gru kind {gru!r}")
+        self.gru = gru
+        self.desc = UpdateBlockDesc(hidden_dim, context_dim, cor_planes, flow_channels, mask_channels,
+                                    0 if gru == "sep_conv" else 1)
+        n = lib.nnd_update_block_packed_floats(C.byref(self.desc))
+        if n <= 0:
+            check(int(n), "update_block_packed_floats")
+        self.packed_floats = int(n)
+        self.packed: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- parameters
+    def pack_host(self, state: dict, prefix: str = "") -> torch.Tensor:
+        """state: {key: tensor}; returns the packed CPU blob (pure host work, no GPU)."""
+        keys = update_block_keys(self.gru)
+        assert len(keys) == lib.nnd_update_block_num_tensors(C.byref(self.desc))
+        hold = [state[prefix + k].detach().to("cpu", torch.float32).contiguous() for k in keys]
+        ptrs = (C.c_void_p * len(hold))(*[t.data_ptr() for t in hold])
+        out = torch.empty(self.packed_floats, dtype=torch.float32)
+        check(lib.nnd_update_block_pack(C.byref(self.desc), ptrs, _p(out)), "update_block_pack")
+        return out
+
+    def load(self, state: dict, prefix: str = "", device="cuda") -> "UpdateBlockEngine":
+        self.packed = self.pack_host(state, prefix).to(device)
+        return self
+
+    # ---- workspace
+    def workspace(self, B: int, H: int, W: int, device) -> torch.Tensor:
+        n = int(lib.nnd_update_block_workspace_floats(C.byref(self.desc), B, H, W))
+        if n <= 0:
+            check(n, "update_block_workspace_floats")
+        if self._ws is None or self._ws.numel() < n or self._ws.device != torch.device(device):
+            self._ws = torch.zeros(n, dtype=torch.float32, device=device)
+        return self._ws
+
+    # ---- ops
+    def forward(self, net, inp, corr, flow, want_mask: bool = True):
+        if self.packed is None:
+            raise NndError("UpdateBlockEngine: parameters not loaded")
+        d = _dev(net, inp, corr, flow, self.packed)
+        net, inp, corr, flow = (t.contiguous() for t in (net, inp, corr, flow))
+        B, _, H, W = net.shape
+        ds = self.desc
+        exp = {"net": (B, ds.hidden_dim, H, W), "inp": (B, ds.context_dim, H, W),
+               "corr": (B, ds.cor_planes, H, W), "flow": (B, ds.flow_channels, H, W)}
+        for name, t in (("net", net), ("inp", inp), ("corr", corr), ("flow", flow)):
+            if tuple(t.shape) != exp[name]:
+                raise NndError(f"update_block: {name} shape {tuple(t.shape)} != {exp[name]}")
+        net_out = torch.empty_like(net)
+        mask = torch.empty((B, ds.mask_channels, H, W), dtype=torch.float32, device=d) if want_mask else None
+        delta = torch.empty_like(flow)
+        ws = self.workspace(B, H, W, d)
+        with torch.cuda.device(d):
+            check(lib.nnd_update_block_forward(C.byref(ds), _p(self.packed), _p(net), _p(inp), _p(corr), _p(flow),
+                                               _p(net_out), _p(mask), _p(delta), _p(ws), B, H, W, _stream(d)),
+                  "update_block_forward")
+        return net_out, mask, delta
+
+    def refine(self, pyr, num_levels: int, radius: int, net, inp, rate: int, iters: int,
+               disp_init=None, keep_all: bool = True):
+        """Fused loop -> (up (iters or 1, B,1,rate*H,rate*W), low (B,1,H,W), net (B,hid,H,W))."""
+        if self.packed is None:
+            raise NndError("UpdateBlockEngine: parameters not loaded")
+        d = _dev(pyr, net, inp, self.packed)
+        net, inp = net.contiguous(), inp.contiguous()
+        B, _, H, W = net.shape
+        n_up = iters if keep_all else 1
+        up = torch.empty((n_up, B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
+        low = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+        net_out = torch.empty_like(net)
+        ws = self.workspace(B, H, W, d)
+        stride = up[0].numel() if keep_all else 0
+        if disp_init is not None:
+            disp_init = disp_init.contiguous()
+        with torch.cuda.device(d):
+            check(lib.nnd_raft_stereo_refine(C.byref(self.desc), _p(self.packed), _p(pyr), num_levels, radius,
+                                             _p(net), _p(inp), _p(disp_init), _p(up), stride, _p(low), _p(net_out),
+                                             _p(ws), B, H, W, rate, iters, _stream(d)), "raft_stereo_refine")
+        return up, low, net_out
+
+    # ---- profiling (bench.py roofline)
+    def conv_names(self) -> List[str]:
+        n = lib.nnd_num_convs(C.byref(self.desc))
+        names = [lib.nnd_conv_name(C.byref(self.desc), i).decode() for i in range(n)]
+        if self.gru != "sep_conv":
+            names = [x for x in names if not x.endswith("2+convr2") and not x.endswith("convq2")]
+        return names
+
+    def profile_conv(self, which: int, B: int, H: int, W: int, reps: int, device) -> Tuple[float, float]:
+        """-> (avg ms per launch measured with hipEvents on the launch stream, algorithmic FLOPs)."""
+        ws = self.workspace(B, H, W, device)
+        ms, fl = C.c_float(), C.c_double()
+        d = torch.device(device)
+        with torch.cuda.device(d):
+            check(lib.nnd_profile_conv(C.byref(self.desc), _p(self.packed), _p(ws), B, H, W, which, reps, _stream(d),
+                                       C.byref(ms), C.byref(fl)), "profile_conv")
+        return ms.value, fl.value

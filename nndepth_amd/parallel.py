@@ -1,0 +1,57 @@
+"""Batch-parallel inference over the GPUs of one node.
+
+Every stereo pair is independent at inference, so the path shards by batch with NO collective
+inside forward(); the only exchange is one all-gather of the final disparity maps
+(`backend="nccl"` is RCCL over xGMI on ROCm; the CPU tests use gloo).  One process per GPU,
+launched by `python -m torch.distributed.run`.
+"""
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_distributed(backend: str = "nccl") -> Tuple[int, int, int]:
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous slice of `n_items` owned by `rank` (first n%world ranks get one extra)."""
+    q, r = divmod(n_items, world)
+    start = rank * q + min(rank, r)
+    return range(start, start + q + (1 if rank < r else 0))
+
+
+def gather_disparity(local: torch.Tensor) -> torch.Tensor:
+    """All-gather equally-shaped per-rank disparity batches (b,1,H,W) -> (world*b,1,H,W), rank order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def max_over_ranks(seconds: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

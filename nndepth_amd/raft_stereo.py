@@ -1,0 +1,115 @@
+"""RAFT-Stereo with the MI355X-native hot path.
+
+`BaseRAFTStereo` keeps the reference's constructor kwargs (= `BaseRAFTStereoModelConfig.to_dict()`,
+nndepth/models/raft_stereo/configs.py:11-23), `state_dict()` keys and `forward(frame1, frame2)
+-> List[{"up_disp": Tensor}]` (nndepth/models/raft_stereo/model.py:17-163), so the reference's
+inference / evaluate scripts can use it unchanged.  Inside `forward()`:
+
+    encoder + cnet_proj      PyTorch-ROCm (adjacent row)
+    corr pyramid build       HIP  (csrc/corr1d.hip)                     model.py:124
+    for iters: lookup -> update block -> coords += delta -> convex upsample
+                             HIP, ONE C-ABI call for the whole loop     model.py:130-137
+                             (csrc/update_block.hip: nnd_raft_stereo_refine)
+
+`patch(model)` installs the same kernels behind the three duck-typed seams of an *unmodified*
+reference model instance: `corr_fn`, `update_block`, `convex_upsample`.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .blocks import BasicUpdateBlock
+from .cost_volume import CorrBlock1D
+from .encoder import BasicEncoder
+from .upsample import convex_upsample
+
+
+def load_weights(model: nn.Module, weights: str, strict_load: bool = True) -> nn.Module:
+    """.pth / .safetensors, like nndepth/utils/common.py:8-16."""
+    if weights.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        state = load_file(weights, device="cpu")
+    else:
+        state = torch.load(weights, map_location="cpu")
+    model.load_state_dict(state, strict=strict_load)
+    return model
+
+
+class BaseRAFTStereo(nn.Module):
+    def __init__(self, iters: int = 12, fnet_dim: int = 256, hidden_dim: int = 128, context_dim: int = 128,
+                 corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
+                 include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
+                 fused_loop: bool = True, **kwargs):
+        super().__init__()
+        self.iters, self.fnet_dim, self.hidden_dim, self.context_dim = iters, fnet_dim, hidden_dim, context_dim
+        self.corr_levels, self.corr_radius = corr_levels, corr_radius
+        self.tracing, self.include_preprocessing = tracing, include_preprocessing
+        self.fused_loop = fused_loop
+        self.fnet = BasicEncoder(output_dim=fnet_dim)
+        self.cnet_proj = nn.Sequential(nn.Conv2d(fnet_dim, context_dim + hidden_dim, 3, padding=1), nn.ReLU(False))
+        self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=corr_levels * (2 * corr_radius + 1),
+                                             flow_channel=1, context_dim=context_dim, spatial_scale=8)
+        self.corr_fn = CorrBlock1D
+        self.weights, self.strict_load = weights, strict_load
+        if weights is not None:
+            load_weights(self, weights, strict_load)
+
+    # seams kept as methods so callers that monkey-patch them keep working
+    def convex_upsample(self, flow, mask, rate=8):
+        return convex_upsample(flow, mask, rate)
+
+    def initialize_coords(self, fmap1):
+        B, _, H, W = fmap1.shape
+        return torch.arange(W, device=fmap1.device).float()[None, None, None, :].repeat(B, 1, H, 1)
+
+    def forward_fnet(self, frame1, frame2):
+        fmap1, fmap2 = self.fnet([frame1, frame2])
+        return fmap1, fmap2, self.cnet_proj(fmap1)
+
+    @torch.no_grad()
+    def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
+        fmap1, fmap2, cnet = self.forward_fnet(frame1, frame2)
+        rate = frame1.shape[-1] // fmap1.shape[-1]
+        fmap1, fmap2 = fmap1.float(), fmap2.float()
+        net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+        corr = self.corr_fn(fmap1, fmap2, self.corr_levels, self.corr_radius)
+        if self.fused_loop and isinstance(corr, CorrBlock1D):
+            eng = self.update_block.sync_engine(frame1.device)
+            up, _, _ = eng.refine(corr._pyr, self.corr_levels, self.corr_radius, net.float(), inp.float(),
+                                  rate, self.iters, keep_all=True)
+            return [{"up_disp": up[i]} for i in range(self.iters)]
+        # seam-by-seam loop (same shape as the reference's), every step still a HIP kernel
+        coords1 = self.initialize_coords(fmap1)
+        org = self.initialize_coords(fmap1)
+        outs = []
+        for _ in range(self.iters):
+            sampled = corr(coords1)
+            net, mask, delta = self.update_block(net, inp, sampled, coords1 - org)
+            coords1 = coords1 + delta
+            outs.append({"up_disp": self.convex_upsample(coords1 - org, mask, rate=rate)})
+        return outs
+
+
+STEREO_MODELS = {"base-raft-stereo": BaseRAFTStereo}
+
+
+def patch(model: nn.Module) -> nn.Module:
+    """Swap the HIP hot path into a reference-style RAFT-Stereo instance in place:
+    `corr_fn`, `update_block` (state_dict carried over) and `convex_upsample`."""
+    old = model.update_block
+    sd = old.state_dict()
+    hid = sd["flow_head.conv1.weight"].shape[0]
+    gin = sd["gru.convz1.weight"].shape[1]
+    new = BasicUpdateBlock(hidden_dim=hid, cor_planes=sd["encoder.convc1.weight"].shape[1],
+                           context_dim=gin - 2 * hid,
+                           gru="sep_conv" if "gru.convz2.weight" in sd else "conv_gru",
+                           flow_channel=sd["flow_head.conv2.weight"].shape[0],
+                           spatial_scale=int(round((sd["mask.2.weight"].shape[0] // 9) ** 0.5)))
+    new.load_state_dict(sd, strict=True)
+    new.to(next(old.parameters()).device)
+    model.update_block = new
+    model.corr_fn = CorrBlock1D
+    model.convex_upsample = lambda flow, mask, rate=8: convex_upsample(flow, mask, rate)
+    return model
