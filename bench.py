@@ -28,6 +28,22 @@ H_IMG, W_IMG, ITERS = 544, 960, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,8 +77,11 @@ def main():
             final = parallel.gather_disparity(final)
         return out, final
 
+    log(f"rank {rank}/{world}: model + inputs resident on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         step()
+        torch.cuda.synchronize(dev)
+        log("warm-up step done")
     torch.cuda.synchronize(dev)
     parallel.barrier()
     torch.cuda.synchronize(dev)
@@ -73,6 +92,7 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
 
     result = {
         "metric": "stereo pairs/sec at 544x960, 32 iters (RAFT-Stereo)",
@@ -97,6 +117,7 @@ def main():
         Hf, Wf = H_IMG // 8, W_IMG // 8
         names = eng.conv_names()
         rows, tot_ms, tot_fl = [], 0.0, 0.0
+        log("roofline: per-conv hipEvent timing")
         for i, nm in enumerate(names):
             ms, fl = eng.profile_conv(i, 1, Hf, Wf, 20, dev)
             rows.append({"conv": nm, "ms": ms, "gflop": fl / 1e9, "tflops": fl / ms / 1e9})
@@ -116,8 +137,9 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (oracle port)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle import torch_ref as R  # checker / baseline only — never on the product path
-        ncpu = os.cpu_count() or 1
+        ncpu = usable_cores()
         torch.set_num_threads(ncpu)
+        log(f"cpu baseline on {ncpu} cores (oracle port, PyTorch CPU eager)")
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         c1, c2 = f1.cpu(), f2.cpu()
         with torch.no_grad():
@@ -128,6 +150,7 @@ def main():
                 R.raft_stereo_forward(sd, c1, c2, ITERS)
                 t_cpu += time.perf_counter() - t1
                 n += 1
+                log(f"cpu forward {n}: {t_cpu:.1f} s total")
         result["cpu_baseline"] = {
             "value": n / t_cpu, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} full forwards of the same 544x960 / 32-iter pair (oracle/torch_ref.py, PyTorch CPU eager fp32)",
