@@ -28,7 +28,7 @@ namespace nnd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MAX_NE = 16;  // patch elements staged per thread per chunk (host checks)
+constexpr int MAX_NE = 8;   // patch elements staged per thread per chunk (host checks)
 
 struct ConvArgs {
     const float* src0;
@@ -44,35 +44,44 @@ struct ConvArgs {
     const float* aux1;
     long abs0, abs1;
     int H, W, Cout, nchunks, epi, hidden;
-    int log2_sc, tiles_x, S, ne;
+    int log2_sc, tiles_x, S, wco, ks;
     float scale;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// Workgroup = wco x ks waves.  Wave (cbi, kj): output-channel block cb = blockIdx.y*wco + cbi, and K-slice kj:
+// of every "super-chunk" of ks*CI_T input channels staged in LDS it multiplies channels [kj*CI_T, (kj+1)*CI_T).
+// The ks partial accumulators of a tile are summed through LDS at the end (intra-workgroup split-K): this is
+// what lets 255 pixel tiles x ncb channel blocks fill 1024 SIMDs evenly at batch 1.
 template <int KH, int KW, int CI_T, int P>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     constexpr int NT = KH * KW;
     constexpr int NQ = CI_T / 8;  // float4 A fragments per lane per (chunk, tap)
     extern __shared__ float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x;
+    const int wco = a.wco, ks = a.ks;
+    const int cbi = wave % wco, kj = wave / wco;
     const int h2 = lane >> 5, l31 = lane & 31;
     const int SC = 1 << a.log2_sc, SR = 32 >> a.log2_sc;
     const int r = l31 >> a.log2_sc, c = l31 & (SC - 1);
     const int tx0 = (blockIdx.x % a.tiles_x) * (P * SC);
     const int ty0 = (blockIdx.x / a.tiles_x) * SR;
-    const int cb = blockIdx.y * (nthreads >> 6) + wave;
+    const int cb = blockIdx.y * wco + cbi;
+    const bool active = cb * 32 < a.Cout;  // trailing waves of the last workgroup only help staging
     const int b = blockIdx.z;
     const int H = a.H, W = a.W;
     const long HW = (long)H * W;
     const int PR = SR + KH - 1, PC = P * SC + KW - 1, S = a.S, PATCH = PR * S;
     constexpr int PH = KH / 2, PW = KW / 2;
+    const int SCH = ks * CI_T;  // channels per super-chunk
 
-    // ---- per-thread staging descriptors (identical for every chunk)
-    int goff[MAX_NE], meta[MAX_NE];
-    const int total = CI_T * PR * PC;
+    // ---- per-thread staging descriptors (identical for every super-chunk).  Loads are unconditional
+    // (clamped to element 0 of the source when masked) so that hipcc counts vmcnt exactly.
+    int goff[MAX_NE], loff[MAX_NE], cflag[MAX_NE];
+    const int total = SCH * PR * PC;
 #pragma unroll
     for (int i = 0; i < MAX_NE; ++i) {
         int e = tid + i * nthreads;
@@ -81,9 +90,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
         int pr = rem / PC, pc = rem - pr * PC;
         int gy = ty0 + pr - PH, gx = tx0 + pc - PW;
         bool inimg = (e < total) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[i] = (int)(ci * HW + (long)gy * W + gx);
-        int loff = ci * PATCH + pr * S + pc;
-        meta[i] = (e < total) ? (loff | ((inimg ? ci : 127) << 24)) : -1;
+        goff[i] = inimg ? (int)(ci * HW + (long)gy * W + gx) : 0;
+        loff[i] = (e < total) ? ci * PATCH + pr * S + pc : -1;
+        cflag[i] = inimg ? ci : 0x7fff;  // 0x7fff: outside the image / not owned -> never < climit
     }
 
     f32x16 acc[P];
@@ -92,14 +101,14 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[pp][i] = 0.f;
 
-    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + (size_t)cb * a.nchunks * (NT * NQ * 64) + lane;
-    float4 a_cur[NT * NQ], a_nxt[NT * NQ];
+    const int nchunks = a.nchunks;
+    const int nsuper = (nchunks + ks - 1) / ks;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + (size_t)(active ? cb : 0) * nchunks * (NT * NQ * 64) + lane;
+    float4 a0[NT * NQ], a1[NT * NQ];
     float stage[MAX_NE];
 
-    auto load_x = [&](int k) {
-        int cbase = k * CI_T;
-        const float* src;
-        int climit;
+    auto chunk_src = [&](int K, const float*& src, int& climit) {
+        int cbase = K * SCH;
         if (cbase < a.c0) {
             src = a.src0 + b * a.bs0 + (long)cbase * HW;
             climit = a.c0 - cbase;
@@ -108,65 +117,110 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
             src = a.src1 + b * a.bs1 + (long)cc * HW;
             climit = a.c1 - cc;
         }
-        climit = climit < CI_T ? climit : CI_T;  // marker 127 (outside the image / not owned) never passes
-#pragma unroll
-        for (int i = 0; i < MAX_NE; ++i) {
-            int ci = (meta[i] >> 24) & 127;
-            stage[i] = (ci < climit) ? src[goff[i]] : 0.f;
-        }
     };
-    auto store_x = [&](int buf) {
-        float* dst = lds + buf * (CI_T * PATCH);
+    // raw loads only: the zero-fill select is applied in store_x, AFTER the chunk's MFMAs, so no
+    // s_waitcnt lands between the prefetch and the multiply
+    auto load_x = [&](int K) {
+        const float* src;
+        int climit;
+        chunk_src(K, src, climit);
+#pragma unroll
+        for (int i = 0; i < MAX_NE; ++i) stage[i] = src[cflag[i] < climit ? goff[i] : 0];
+    };
+    auto store_x = [&](int K) {
+        const float* src;
+        int climit;
+        chunk_src(K, src, climit);
+        float* dst = lds + (K & 1) * (SCH * PATCH);
 #pragma unroll
         for (int i = 0; i < MAX_NE; ++i)
-            if (meta[i] != -1) dst[meta[i] & 0xFFFFFF] = stage[i];
+            if (loff[i] >= 0) dst[loff[i]] = cflag[i] < climit ? stage[i] : 0.f;
     };
-    auto load_a = [&](float4* dstv, int k) {
+    // chunk index of this wave inside super-chunk K; waves past the last real chunk load chunk 0 (harmless)
+    auto load_a = [&](float4* dstv, int K) {
+        int ch = K * ks + kj;
+        ch = ch < nchunks ? ch : 0;
 #pragma unroll
-        for (int t = 0; t < NT * NQ; ++t) dstv[t] = wp[(size_t)(k * (NT * NQ) + t) * 64];
+        for (int t = 0; t < NT * NQ; ++t) dstv[t] = wp[(size_t)(ch * (NT * NQ) + t) * 64];
     };
 
-    load_a(a_cur, 0);
+    const int lane_base = kj * (CI_T * PATCH) + h2 * PATCH + r * S + c;
+
+    // one super-chunk: prefetch K+1 (A fragments -> nxt, patch -> stage), multiply this wave's slice of K from LDS
+    auto chunk = [&](int K, const float4* cur, float4* nxt) {
+        const bool more = (K + 1 < nsuper);
+        if (more) {
+            load_a(nxt, K + 1);
+            load_x(K + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (K * ks + kj < nchunks) {
+            const float* xb = lds + (K & 1) * (SCH * PATCH) + lane_base;
+            // B operands are read one tap ahead of the MFMAs that consume them (register double buffer),
+            // so the LDS latency of tap t+1 hides under the 4*NQ*P MFMAs of tap t.
+            float bq[2][NQ * 4 * P];
+            auto read_tap = [&](int t, float* dst) {
+                const int dy = t / KW, dx = t % KW;
+#pragma unroll
+                for (int pair = 0; pair < NQ * 4; ++pair)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp) dst[pair * P + pp] = xb[(pair * 2) * PATCH + dy * S + dx + pp * SC];
+            };
+            read_tap(0, bq[0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t + 1 < NT) read_tap(t + 1, bq[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float4 av = cur[t * NQ + q];
+                    const float avs[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp)
+                            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[j], bq[t & 1][(q * 4 + j) * P + pp], acc[pp], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_x(K + 1);
+        __syncthreads();
+    };
+
+    load_a(a0, 0);
     load_x(0);
     store_x(0);
     __syncthreads();
+    for (int K = 0; K < nsuper; K += 2) {
+        chunk(K, a0, a1);
+        if (K + 1 < nsuper) chunk(K + 1, a1, a0);
+    }
 
-    const int lane_base = h2 * PATCH + r * S + c;
-    const int nchunks = a.nchunks;
-    for (int k = 0; k < nchunks; ++k) {
-        const bool more = (k + 1 < nchunks);
-        if (more) {
-            load_x(k + 1);
-            load_a(a_nxt, k + 1);
-        }
-        const float* xb = lds + (k & 1) * (CI_T * PATCH) + lane_base;
+    // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier)
+    if (ks > 1) {
+        if (kj > 0 && active) {
+            float* red = lds + (size_t)((cbi * (ks - 1) + (kj - 1)) * P) * 1024 + lane;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int dy = t / KW, dx = t % KW;
+            for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float4 av = a_cur[t * NQ + q];
-                const float avs[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pair = q * 4 + j;
-#pragma unroll
-                    for (int pp = 0; pp < P; ++pp) {
-                        float bv = xb[(pair * 2) * PATCH + dy * S + dx + pp * SC];
-                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[j], bv, acc[pp], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (more) {
-            store_x((k + 1) & 1);
-#pragma unroll
-            for (int t = 0; t < NT * NQ; ++t) a_cur[t] = a_nxt[t];
+                for (int reg = 0; reg < 16; ++reg) red[pp * 1024 + reg * 64] = acc[pp][reg];
         }
         __syncthreads();
+        if (kj == 0 && active) {
+            for (int j = 1; j < ks; ++j) {
+                const float* red = lds + (size_t)((cbi * (ks - 1) + (j - 1)) * P) * 1024 + lane;
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[pp][reg] += red[pp * 1024 + reg * 64];
+            }
+        }
     }
 
     // ---- epilogue: lane holds pixel (y, x_pp) and 16 output channels
+    if (!active || kj != 0) return;
     const int y = ty0 + r;
     const int epi = a.epi;
 #pragma unroll
@@ -205,42 +259,62 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 
 // --------------------------------------------------------------------------- host side
 struct TileCfg {
-    int log2_sc, P, wco, tiles_x, tiles_y, S, ne;
+    int log2_sc, P, wco, ks, tiles_x, tiles_y, S;
+    size_t lds;
 };
 
-static bool pick_tile(const ConvLayer& L, int B, int H, int W, TileCfg* out) {
-    int wco = 1;
-    for (int w : {4, 3, 2, 1})
-        if (L.ncb % w == 0) {
-            wco = w;
-            break;
-        }
-    int force_sc = -1, force_p = -1;
-    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d", &force_sc, &force_p);
+// Chooses the pixel sub-tile shape (SR x SC), P sub-tiles per wave, wco x ks waves per workgroup.
+// Cost model: every wave issues unit = ceil(nchunks/ks) * P MFMA streams; waves spread evenly over the
+// 1024 SIMDs of the chip, so the busiest SIMD runs ceil(waves/1024) * unit (quantisation is what matters
+// at batch 1: 68x120 = 255 tiles of 4x8 pixels).
+static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, TileCfg* out) {
+    int force_sc = -1, force_p = -1, force_ks = -1;
+    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &force_sc, &force_p, &force_ks);
     double best = 1e30;
     bool found = false;
-    for (int log2_sc : {3, 4, 5, 2}) {
-        for (int P : {1, 2, 3}) {
-            if (force_sc >= 0 && log2_sc != force_sc) continue;
-            if (force_p >= 0 && P != force_p) continue;
-            int SC = 1 << log2_sc, SR = 32 >> log2_sc;
-            int tx = cdiv(W, P * SC), ty = cdiv(H, SR);
-            int PR = SR + L.KH - 1, PC = P * SC + L.KW - 1;
-            int S = SC;  // smallest odd multiple of SC >= PC (bank-conflict-free B reads)
-            while (S < PC) S += 2 * SC;
-            int ne = cdiv(L.CI_T * PR * PC, 64 * wco);
-            if (ne > MAX_NE) continue;
-            size_t lds = (size_t)2 * L.CI_T * PR * S * sizeof(float);
-            if (lds > 64 * 1024) continue;
-            double waves = (double)tx * ty * B * L.ncb;
-            double rounds = std::ceil(waves / 1024.0);
-            double t = rounds * P;                       // MFMA streams on the busiest SIMD
-            t *= 1.0 - 0.02 * (P - 1);                   // larger P: fewer weight bytes per flop
-            t *= 1.0 + 0.01 * (5 - log2_sc);             // wider rows coalesce better
-            if (t < best) {
-                best = t;
-                *out = {log2_sc, P, wco, tx, ty, S, ne};
-                found = true;
+    for (int ks : {1, 2, 4}) {
+        if (force_ks > 0 && ks != force_ks) continue;
+        if (ks > L.nchunks) continue;
+        if (c1 > 0 && c0 % (ks * L.CI_T) != 0) continue;
+        // waves per workgroup along Cout: fewest total wave slots, ties -> more sharing of the patch
+        int wco = 1, best_slots = 1 << 30;
+        for (int w : {4, 3, 2, 1}) {
+            if (w * ks > 8) continue;
+            int slots = cdiv(L.ncb, w) * w;
+            if (slots < best_slots) {
+                best_slots = slots;
+                wco = w;
+            }
+        }
+        if (L.ncb == 1 && ks == 1) wco = 2;  // one idle wave helps stage the patch
+        for (int log2_sc : {3, 4, 5, 2}) {
+            for (int P : {1, 2, 3}) {
+                if (force_sc >= 0 && log2_sc != force_sc) continue;
+                if (force_p > 0 && P != force_p) continue;
+                int SC = 1 << log2_sc, SR = 32 >> log2_sc;
+                int tx = cdiv(W, P * SC), ty = cdiv(H, SR);
+                int PR = SR + L.KH - 1, PC = P * SC + L.KW - 1;
+                int S = SC;  // smallest odd multiple of SC >= PC (bank-conflict-free B reads)
+                while (S < PC) S += 2 * SC;
+                if (cdiv(ks * L.CI_T * PR * PC, 64 * wco * ks) > MAX_NE) continue;
+                size_t lds = (size_t)2 * ks * L.CI_T * PR * S * sizeof(float);
+                size_t red = (size_t)wco * (ks - 1) * P * 1024 * sizeof(float);
+                if (red > lds) lds = red;
+                if (lds > 64 * 1024) continue;
+                const int occ = P == 1 ? 4 : 2;  // resident waves per SIMD the register budget allows
+                double waves = (double)tx * ty * B * cdiv(L.ncb, wco) * wco * ks;
+                double unit = (double)cdiv(L.nchunks, ks) * P;
+                double per_simd = std::ceil(waves / 1024.0);
+                double t = (per_simd <= occ) ? per_simd * unit : std::ceil(waves / (1024.0 * occ)) * occ * unit;
+                if (waves <= 1024.0) t *= 1.10;             // one wave per SIMD cannot hide its own stalls
+                t *= 1.0 - 0.02 * (P - 1);                   // larger P: fewer weight bytes per flop
+                t *= 1.0 + 0.01 * (5 - log2_sc);             // wider rows coalesce better
+                t *= 1.0 + 0.01 * (ks - 1);                  // reduction cost
+                if (t < best) {
+                    best = t;
+                    *out = {log2_sc, P, wco, ks, tx, ty, S, lds};
+                    found = true;
+                }
             }
         }
     }
@@ -264,7 +338,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     NND_REQUIRE(io.src1.C == 0 || io.src0.C % L.CI_T == 0, "conv: first source (%d ch) must be a multiple of %d", io.src0.C, L.CI_T);
     NND_REQUIRE((long)L.Cin * H * W < (1L << 31), "conv: plane offsets exceed 32 bits");
     TileCfg cfg;
-    NND_REQUIRE(pick_tile(L, B, H, W, &cfg), "conv: no tile configuration for %dx%d Cin=%d", L.KH, L.KW, L.Cin);
+    NND_REQUIRE(pick_tile(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv: no tile configuration for %dx%d Cin=%d", L.KH, L.KW, L.Cin);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src0 = io.src0.ptr; a.bs0 = io.src0.bstride; a.c0 = io.src0.C;
@@ -276,11 +350,13 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
-    a.log2_sc = cfg.log2_sc; a.tiles_x = cfg.tiles_x; a.S = cfg.S; a.ne = cfg.ne;
+    a.log2_sc = cfg.log2_sc; a.tiles_x = cfg.tiles_x; a.S = cfg.S; a.wco = cfg.wco; a.ks = cfg.ks;
     a.scale = io.scale;
-    const int SR = 32 >> cfg.log2_sc;
-    size_t lds = (size_t)2 * L.CI_T * (SR + L.KH - 1) * cfg.S * sizeof(float);
-    dim3 grid(cfg.tiles_x * cfg.tiles_y, L.ncb / cfg.wco, B), block(64 * cfg.wco);
+    const size_t lds = cfg.lds;
+    dim3 grid(cfg.tiles_x * cfg.tiles_y, cdiv(L.ncb, cfg.wco), B), block(64 * cfg.wco * cfg.ks);
+    if (getenv("NND_CONV_VERBOSE"))
+        fprintf(stderr, "[nnd] conv %dx%d Cin=%d Cout=%d: tile 2^%d cols, P=%d, wco=%d, ks=%d, grid %ux%ux%u, lds %zu B\n", L.KH,
+                L.KW, L.Cin, L.Cout, cfg.log2_sc, cfg.P, cfg.wco, cfg.ks, grid.x, grid.y, grid.z, lds);
     bool launched = false;
     NND_CONV_CASE(1, 1, 8)
     NND_CONV_CASE(1, 1, 32)
