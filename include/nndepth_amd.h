@@ -140,6 +140,9 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
 int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed_dev, float* workspace,
                      int B, int H, int W, int which, int reps, void* stream,
                      float* ms_out, double* flops_out);
+/* Diagnostic: sustained fp32-MFMA rate of this device (dependent v_mfma_f32_32x32x2 chains, no memory
+ * traffic) at `waves_per_simd` resident waves; `scratch_dev` is any device buffer of >= 1 float.        */
+int nnd_profile_mfma_peak(int waves_per_simd, int iters, void* stream, float* scratch_dev, float* tflops_out);
 int nnd_num_convs(const nnd_update_block_desc* desc);
 const char* nnd_conv_name(const nnd_update_block_desc* desc, int which);
 

@@ -52,7 +52,7 @@ enum ConvEpilogue {
 
 // One convolution layer inside a packed parameter blob.
 struct ConvLayer {
-    int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (8 or 32)
+    int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (32, or 128 for wide 1x1)
     int nchunks;                  // ceil(Cin / CI_T)
     int ncb;                      // ceil(Cout / 32) output-channel blocks
     int64_t w_off, b_off;         // float offsets in the blob
@@ -75,6 +75,9 @@ struct ConvIO {
     int hidden = 0;
     float scale = 1.f;
 };
+
+// input channels per K-chunk for a layer shape (host packer and kernels must agree)
+int conv_ci_t(int KH, int KW, int Cin);
 
 int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi,
                 int B, int H, int W, hipStream_t stream);

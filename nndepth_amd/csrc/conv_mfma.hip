@@ -2,19 +2,24 @@
 //
 //   out[b, co, y, x] = epilogue( bias[co] + sum_{ci,dy,dx} W[co,ci,dy,dx] * in[b, ci, y+dy-ph, x+dx-pw] )
 //
-// Mapping (D = A*B with v_mfma_f32_32x32x2_f32, exact fp32 fmaf chain):
-//   A = weights   A[i = co (32 per wave)][k]      streamed global -> VGPR, pre-packed on the host in
-//                                                 fragment order (one coalesced 1 KiB dwordx4 load per
-//                                                 wave per (chunk, tap, 8 channels)); never touches LDS
-//   B = activations B[k][j = pixel (32 per MFMA)] staged once per workgroup as a zero-filled halo
-//                                                 patch in LDS and shared by all waves / all taps
-//   D[i = co][j = pixel]: a lane holds ONE pixel and 16 output channels, so NCHW stores are
-//   32 consecutive pixels per (register, half-wave) and the GRU gate math is a pure per-lane epilogue.
-// The 32 pixels of an MFMA column block form an SR x SC sub-tile (SR*SC = 32; 4x8 tiles 68x120 exactly),
-// each wave owns P such sub-tiles side by side (P accumulators), the waves of a workgroup own
-// consecutive 32-channel output blocks and share the pixel tile.
-// K is walked in chunks of CI_T input channels x all taps; the patch of chunk k+1 and the A fragments
-// of chunk k+1 are prefetched into registers while chunk k is multiplied (one barrier per chunk).
+// Mapping (D = A*B with v_mfma_f32_32x32x2_f32, an exact fp32 fmaf chain):
+//   A = weights     A[i = co (32 per wave)][k]     streamed global -> VGPR, pre-packed on the host in
+//                                                  fragment order (one coalesced 1 KiB dwordx4 load per wave per
+//                                                  8 input channels of one tap); never touches LDS
+//   B = activations B[k][j = pixel (32 per MFMA)]  staged once per workgroup as a zero-filled halo patch in
+//                                                  LDS, shared by all waves and all taps
+//   D[i = co][j = pixel]: a lane holds ONE pixel and 16 output channels, so NCHW stores are 32 consecutive
+//   pixels per (register, half-wave) and the GRU gate math is a pure per-lane epilogue.
+// The 32 pixels of an MFMA column block form a 4-row x 8-col sub-tile (tiles 68x120 exactly: 17 x 15); a
+// wave owns P such sub-tiles side by side (P accumulators).
+// Workgroup = wco x ks waves.  Wave (cbi, kj) owns output-channel block blockIdx.y*wco + cbi and K-slice kj:
+// of every super-chunk of ks*CI_T input channels staged in LDS it multiplies channels [kj*CI_T, (kj+1)*CI_T);
+// the ks partial accumulators are summed through LDS at the end (intra-workgroup split-K) — this is what lets
+// 255 pixel tiles x ncb channel blocks load 1024 SIMDs evenly at batch 1.
+// Pipeline: a chunk is walked in steps of (tap, 32-channel group) = 16*P MFMAs; the A fragments and the B
+// operands of step s+1 are fetched (global / LDS) before the MFMAs of step s issue; the patch of the next
+// super-chunk is fetched into registers at the top of a chunk and written to the other LDS buffer at its end
+// (one barrier per super-chunk, i.e. per 16*P*taps*CI_T/32 MFMAs per wave).
 //
 // Replaces the nn.Conv2d calls of nndepth/blocks/update_block.py:57-65,26-36,97-112 and
 // nndepth/blocks/gru.py:22-37,53-61 (reference files; semantics restated in oracle/torch_ref.py).
@@ -23,12 +28,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace nnd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int MAX_NE = 8;   // patch elements staged per thread per chunk (host checks)
 
 struct ConvArgs {
     const float* src0;
@@ -44,29 +48,31 @@ struct ConvArgs {
     const float* aux1;
     long abs0, abs1;
     int H, W, Cout, nchunks, epi, hidden;
-    int log2_sc, tiles_x, S, wco, ks;
+    int tiles_x, wco, ks, npos, ngroups;
     float scale;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// Workgroup = wco x ks waves.  Wave (cbi, kj): output-channel block cb = blockIdx.y*wco + cbi, and K-slice kj:
-// of every "super-chunk" of ks*CI_T input channels staged in LDS it multiplies channels [kj*CI_T, (kj+1)*CI_T).
-// The ks partial accumulators of a tile are summed through LDS at the end (intra-workgroup split-K): this is
-// what lets 255 pixel tiles x ncb channel blocks fill 1024 SIMDs evenly at batch 1.
-template <int KH, int KW, int CI_T, int P>
+// NE: patch elements staged per thread per super-chunk (the thread owns one patch position and NE channels)
+template <int KH, int KW, int CI_T, int P, int NE>
 __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     constexpr int NT = KH * KW;
-    constexpr int NQ = CI_T / 8;  // float4 A fragments per lane per (chunk, tap)
+    constexpr int SG = CI_T < 32 ? CI_T : 32;  // channels per pipeline step
+    constexpr int NGRP = CI_T / SG;            // channel groups per tap
+    constexpr int NS = NT * NGRP;              // steps per chunk
+    constexpr int AQ = SG / 8;                 // float4 A fragments per lane per step
+    constexpr int NB = SG / 2 * P;             // MFMAs (= B operands) per step
+    constexpr int PH = KH / 2, PW = KW / 2;
     extern __shared__ float lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nthreads = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar address math
     const int wco = a.wco, ks = a.ks;
     const int cbi = wave % wco, kj = wave / wco;
     const int h2 = lane >> 5, l31 = lane & 31;
-    const int SC = 1 << a.log2_sc, SR = 32 >> a.log2_sc;
-    const int r = l31 >> a.log2_sc, c = l31 & (SC - 1);
+    constexpr int SC = 8, SR = 4;  // MFMA column block = 4 rows x 8 cols of pixels
+    const int r = l31 >> 3, c = l31 & 7;
     const int tx0 = (blockIdx.x % a.tiles_x) * (P * SC);
     const int ty0 = (blockIdx.x / a.tiles_x) * SR;
     const int cb = blockIdx.y * wco + cbi;
@@ -74,26 +80,22 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     const int b = blockIdx.z;
     const int H = a.H, W = a.W;
     const long HW = (long)H * W;
-    const int PR = SR + KH - 1, PC = P * SC + KW - 1, S = a.S, PATCH = PR * S;
-    constexpr int PH = KH / 2, PW = KW / 2;
+    // LDS patch geometry is compile-time so every B-operand read is base + immediate offset.
+    // Row stride S is an odd multiple of SC: lanes (r, c) then hit 32 distinct banks.
+    constexpr int PR = SR + KH - 1, PC = P * SC + KW - 1;
+    constexpr int S = PC <= 8 ? 8 : (PC <= 24 ? 24 : 40), PATCH = PR * S;
     const int SCH = ks * CI_T;  // channels per super-chunk
 
-    // ---- per-thread staging descriptors (identical for every super-chunk).  Loads are unconditional
-    // (clamped to element 0 of the source when masked) so that hipcc counts vmcnt exactly.
-    int goff[MAX_NE], loff[MAX_NE], cflag[MAX_NE];
-    const int total = SCH * PR * PC;
-#pragma unroll
-    for (int i = 0; i < MAX_NE; ++i) {
-        int e = tid + i * nthreads;
-        int ci = e / (PR * PC);
-        int rem = e - ci * (PR * PC);
-        int pr = rem / PC, pc = rem - pr * PC;
-        int gy = ty0 + pr - PH, gx = tx0 + pc - PW;
-        bool inimg = (e < total) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[i] = inimg ? (int)(ci * HW + (long)gy * W + gx) : 0;
-        loff[i] = (e < total) ? ci * PATCH + pr * S + pc : -1;
-        cflag[i] = inimg ? ci : 0x7fff;  // 0x7fff: outside the image / not owned -> never < climit
-    }
+    // ---- staging role of this thread: patch position `pos`, channels cg, cg+ngroups, ... (NE of them)
+    const int npos = a.npos, ngroups = a.ngroups;
+    const int pos = tid % npos, cg = tid / npos;
+    const bool stager = cg < ngroups;
+    const int pr = pos / PC, pc = pos - pr * PC;
+    const int gy = ty0 + pr - PH, gx = tx0 + pc - PW;
+    const bool inimg = stager && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int goff0 = inimg ? gy * W + gx : 0;
+    const int loff0 = pr * S + pc;
+    const int trash = 2 * SCH * PATCH;  // one spare LDS word swallows the stores of non-staging threads
 
     f32x16 acc[P];
 #pragma unroll
@@ -103,9 +105,9 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
 
     const int nchunks = a.nchunks;
     const int nsuper = (nchunks + ks - 1) / ks;
-    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + (size_t)(active ? cb : 0) * nchunks * (NT * NQ * 64) + lane;
-    float4 a0[NT * NQ], a1[NT * NQ];
-    float stage[MAX_NE];
+    // uniform (SGPR) base + 32-bit lane offset: the loads use the saddr form, no per-load VGPR address math
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpk) + (size_t)(active ? cb : 0) * nchunks * (NS * AQ * 64);
+    float stage[NE];
 
     auto chunk_src = [&](int K, const float*& src, int& climit) {
         int cbase = K * SCH;
@@ -118,84 +120,108 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             climit = a.c1 - cc;
         }
     };
-    // raw loads only: the zero-fill select is applied in store_x, AFTER the chunk's MFMAs, so no
-    // s_waitcnt lands between the prefetch and the multiply
+    // raw loads only (clamped to element 0 when masked, so they are unconditional and hipcc counts vmcnt
+    // exactly); the zero-fill select is applied in store_x, after the chunk's MFMAs
     auto load_x = [&](int K) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
+        if (!inimg) climit = 0;
 #pragma unroll
-        for (int i = 0; i < MAX_NE; ++i) stage[i] = src[cflag[i] < climit ? goff[i] : 0];
+        for (int j = 0; j < NE; ++j) {
+            const int ci = cg + j * ngroups;
+            stage[j] = src[ci < climit ? (unsigned)(ci * (int)HW + goff0) : 0u];
+        }
     };
     auto store_x = [&](int K) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
-        float* dst = lds + (K & 1) * (SCH * PATCH);
+        if (!inimg) climit = 0;
+        const int boff = (K & 1) * (SCH * PATCH);
 #pragma unroll
-        for (int i = 0; i < MAX_NE; ++i)
-            if (loff[i] >= 0) dst[loff[i]] = cflag[i] < climit ? stage[i] : 0.f;
+        for (int j = 0; j < NE; ++j) {
+            const int ci = cg + j * ngroups;
+            const bool own = stager && ci < SCH;
+            lds[own ? boff + ci * PATCH + loff0 : trash] = ci < climit ? stage[j] : 0.f;
+        }
     };
-    // chunk index of this wave inside super-chunk K; waves past the last real chunk load chunk 0 (harmless)
-    auto load_a = [&](float4* dstv, int K) {
+
+    // A fragments of this wave's chunk in super-chunk K (waves past the last chunk re-read chunk 0: harmless)
+    auto a_ptr = [&](int K) {
         int ch = K * ks + kj;
         ch = ch < nchunks ? ch : 0;
+        return wbase + (size_t)ch * (NS * AQ * 64);
+    };
+    auto load_a = [&](float4* dstv, const float4* wc, int s) {
+        const float4* ws = wc + s * (AQ * 64);  // scalar base per step; q selects an immediate offset
 #pragma unroll
-        for (int t = 0; t < NT * NQ; ++t) dstv[t] = wp[(size_t)(ch * (NT * NQ) + t) * 64];
+        for (int q = 0; q < AQ; ++q) dstv[q] = ws[(unsigned)(q * 64 + lane)];
     };
 
     const int lane_base = kj * (CI_T * PATCH) + h2 * PATCH + r * S + c;
 
-    // one super-chunk: prefetch K+1 (A fragments -> nxt, patch -> stage), multiply this wave's slice of K from LDS
-    auto chunk = [&](int K, const float4* cur, float4* nxt) {
+    // A fragments ping-pong between two register sets by step parity (rolling prefetch, also across chunk
+    // boundaries); `par` = parity of the first step of the chunk, a compile-time constant per call site.
+    float4 abuf[2][AQ];
+    load_a(abuf[0], a_ptr(0), 0);
+    load_x(0);
+    store_x(0);
+    __syncthreads();
+
+    auto chunk = [&](int K, auto par_c) {
+        constexpr int par = decltype(par_c)::value;
         const bool more = (K + 1 < nsuper);
-        if (more) {
-            load_a(nxt, K + 1);
-            load_x(K + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (K * ks + kj < nchunks) {
-            const float* xb = lds + (K & 1) * (SCH * PATCH) + lane_base;
-            // B operands are read one tap ahead of the MFMAs that consume them (register double buffer),
-            // so the LDS latency of tap t+1 hides under the 4*NQ*P MFMAs of tap t.
-            float bq[2][NQ * 4 * P];
-            auto read_tap = [&](int t, float* dst) {
-                const int dy = t / KW, dx = t % KW;
+        if (more) load_x(K + 1);
+        const float4* wc = a_ptr(K);
+        const float4* wn = a_ptr(more ? K + 1 : K);
+        const bool mine = K * ks + kj < nchunks;
+        const float* xb = lds + (K & 1) * (SCH * PATCH) + lane_base;
+        float bq[2][NB];
+        auto read_step = [&](int s, float* dst) {
+            const int t = s / NGRP, g = s % NGRP;
+            const int dy = t / KW, dx = t % KW;
 #pragma unroll
-                for (int pair = 0; pair < NQ * 4; ++pair)
+            for (int pair = 0; pair < SG / 2; ++pair)
 #pragma unroll
-                    for (int pp = 0; pp < P; ++pp) dst[pair * P + pp] = xb[(pair * 2) * PATCH + dy * S + dx + pp * SC];
-            };
-            read_tap(0, bq[0]);
+                for (int pp = 0; pp < P; ++pp)
+                    dst[pair * P + pp] = xb[(g * SG + pair * 2) * PATCH + dy * S + dx + pp * SC];
+        };
+        read_step(0, bq[0]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t + 1 < NT) read_tap(t + 1, bq[(t + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < NS; ++s) {
+            float4* ac = abuf[(par + s) & 1];
+            float4* an = abuf[(par + s + 1) & 1];
+            if (s + 1 < NS) {
+                load_a(an, wc, s + 1);
+                read_step(s + 1, bq[(s + 1) & 1]);
+            } else {
+                load_a(an, wn, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (mine) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const float4 av = cur[t * NQ + q];
-                    const float avs[4] = {av.x, av.y, av.z, av.w};
+                for (int q = 0; q < AQ; ++q) {
+                    const float avs[4] = {ac[q].x, ac[q].y, ac[q].z, ac[q].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int pp = 0; pp < P; ++pp)
-                            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[j], bq[t & 1][(q * 4 + j) * P + pp], acc[pp], 0, 0, 0);
+                            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[j], bq[s & 1][(q * 4 + j) * P + pp], acc[pp], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (more) store_x(K + 1);
         __syncthreads();
     };
-
-    load_a(a0, 0);
-    load_x(0);
-    store_x(0);
-    __syncthreads();
-    for (int K = 0; K < nsuper; K += 2) {
-        chunk(K, a0, a1);
-        if (K + 1 < nsuper) chunk(K + 1, a1, a0);
+    if constexpr (NS % 2 == 0) {
+        for (int K = 0; K < nsuper; ++K) chunk(K, std::integral_constant<int, 0>{});
+    } else {
+        for (int K = 0; K < nsuper; K += 2) {
+            chunk(K, std::integral_constant<int, 0>{});
+            if (K + 1 < nsuper) chunk(K + 1, std::integral_constant<int, 1>{});
+        }
     }
 
     // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier)
@@ -259,60 +285,58 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
 
 // --------------------------------------------------------------------------- host side
 struct TileCfg {
-    int log2_sc, P, wco, ks, tiles_x, tiles_y, S;
+    int P, wco, ks, tiles_x, tiles_y, npos, ngroups, ne;
     size_t lds;
 };
 
-// Chooses the pixel sub-tile shape (SR x SC), P sub-tiles per wave, wco x ks waves per workgroup.
-// Cost model: every wave issues unit = ceil(nchunks/ks) * P MFMA streams; waves spread evenly over the
-// 1024 SIMDs of the chip, so the busiest SIMD runs ceil(waves/1024) * unit (quantisation is what matters
-// at batch 1: 68x120 = 255 tiles of 4x8 pixels).
+// Chooses the pixel sub-tile shape (SR x SC), P sub-tiles per wave and wco x ks waves per workgroup.
+// Cost model: every wave issues unit = ceil(nchunks/ks) * P MFMA streams; waves spread evenly over the 1024
+// SIMDs of the chip, so the busiest SIMD runs ceil(waves/1024) * unit (quantisation is what matters at
+// batch 1: 68x120 = 255 tiles of 4x8 pixels).
 static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, TileCfg* out) {
-    int force_sc = -1, force_p = -1, force_ks = -1;
-    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &force_sc, &force_p, &force_ks);
+    int force_p = -1, force_ks = -1;
+    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d", &force_p, &force_ks);
     double best = 1e30;
     bool found = false;
-    for (int ks : {1, 2, 4}) {
+    for (int ks : {1, 2})
+    for (int wco : {4, 3, 2, 1}) {
         if (force_ks > 0 && ks != force_ks) continue;
-        if (ks > L.nchunks) continue;
+        if (ks > L.nchunks || wco * ks > 8) continue;
         if (c1 > 0 && c0 % (ks * L.CI_T) != 0) continue;
-        // waves per workgroup along Cout: fewest total wave slots, ties -> more sharing of the patch
-        int wco = 1, best_slots = 1 << 30;
-        for (int w : {4, 3, 2, 1}) {
-            if (w * ks > 8) continue;
-            int slots = cdiv(L.ncb, w) * w;
-            if (slots < best_slots) {
-                best_slots = slots;
-                wco = w;
-            }
-        }
-        if (L.ncb == 1 && ks == 1) wco = 2;  // one idle wave helps stage the patch
-        for (int log2_sc : {3, 4, 5, 2}) {
-            for (int P : {1, 2, 3}) {
-                if (force_sc >= 0 && log2_sc != force_sc) continue;
+        if (wco > 1 && cdiv(L.ncb, wco) * wco >= L.ncb + wco) continue;  // a whole workgroup of idle waves
+        const int nthreads = 64 * wco * ks;
+        {
+            for (int P : {1, 2}) {
                 if (force_p > 0 && P != force_p) continue;
-                int SC = 1 << log2_sc, SR = 32 >> log2_sc;
+                const int SC = 8, SR = 4;
                 int tx = cdiv(W, P * SC), ty = cdiv(H, SR);
                 int PR = SR + L.KH - 1, PC = P * SC + L.KW - 1;
-                int S = SC;  // smallest odd multiple of SC >= PC (bank-conflict-free B reads)
-                while (S < PC) S += 2 * SC;
-                if (cdiv(ks * L.CI_T * PR * PC, 64 * wco * ks) > MAX_NE) continue;
-                size_t lds = (size_t)2 * ks * L.CI_T * PR * S * sizeof(float);
+                int S = PC <= 8 ? 8 : (PC <= 24 ? 24 : 40);  // must match the kernel's constexpr
+                int npos = PR * PC;
+                if (npos > nthreads) continue;
+                int ngroups = nthreads / npos;
+                int ne = cdiv(ks * L.CI_T, ngroups);
+                if (ne > 16) continue;
+                size_t lds = ((size_t)2 * ks * L.CI_T * PR * S + 1) * sizeof(float);
                 size_t red = (size_t)wco * (ks - 1) * P * 1024 * sizeof(float);
                 if (red > lds) lds = red;
-                if (lds > 64 * 1024) continue;
-                const int occ = P == 1 ? 4 : 2;  // resident waves per SIMD the register budget allows
+                if (lds > 160 * 1024) continue;
+                int occ = P == 1 ? 4 : 2;  // resident waves per SIMD the register budget allows
+                int wg_per_cu = (int)((160 * 1024) / lds);
+                int occ_lds = cdiv(wg_per_cu * wco * ks, 4);
+                if (occ_lds < occ) occ = occ_lds;
+                if (occ < 1) occ = 1;
                 double waves = (double)tx * ty * B * cdiv(L.ncb, wco) * wco * ks;
                 double unit = (double)cdiv(L.nchunks, ks) * P;
                 double per_simd = std::ceil(waves / 1024.0);
                 double t = (per_simd <= occ) ? per_simd * unit : std::ceil(waves / (1024.0 * occ)) * occ * unit;
                 if (waves <= 1024.0) t *= 1.10;             // one wave per SIMD cannot hide its own stalls
+                t *= 1.0 + 0.02 * (4 - wco);                 // fewer waves share one staged patch
                 t *= 1.0 - 0.02 * (P - 1);                   // larger P: fewer weight bytes per flop
-                t *= 1.0 + 0.01 * (5 - log2_sc);             // wider rows coalesce better
                 t *= 1.0 + 0.01 * (ks - 1);                  // reduction cost
                 if (t < best) {
                     best = t;
-                    *out = {log2_sc, P, wco, ks, tx, ty, S, lds};
+                    *out = {P, wco, ks, tx, ty, npos, ngroups, ne, lds};
                     found = true;
                 }
             }
@@ -321,22 +345,35 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
     return found;
 }
 
-#define NND_CONV_CASE(KH_, KW_, CI_)                                                              \
-    if (L.KH == KH_ && L.KW == KW_ && L.CI_T == CI_) {                                            \
-        if (cfg.P == 1)                                                                           \
-            hipLaunchKernelGGL((conv_mfma_kernel<KH_, KW_, CI_, 1>), grid, block, lds, stream, a); \
-        else if (cfg.P == 2)                                                                      \
-            hipLaunchKernelGGL((conv_mfma_kernel<KH_, KW_, CI_, 2>), grid, block, lds, stream, a); \
-        else                                                                                      \
-            hipLaunchKernelGGL((conv_mfma_kernel<KH_, KW_, CI_, 3>), grid, block, lds, stream, a); \
-        launched = true;                                                                          \
+template <int KH, int KW, int CI_T, int P, int NE>
+static int launch_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    auto kern = conv_mfma_kernel<KH, KW, CI_T, P, NE>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;  // per instantiation; idempotent, so a benign race at worst
+        if (!raised) {
+            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
     }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    return NND_OK;
+}
+
+template <int KH, int KW, int CI_T>
+static int launch_shape(const ConvArgs& a, const TileCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
+    if (cfg.P == 1) {
+        if (cfg.ne <= 8) return launch_one<KH, KW, CI_T, 1, 8>(a, grid, block, cfg.lds, stream);
+        return launch_one<KH, KW, CI_T, 1, 16>(a, grid, block, cfg.lds, stream);
+    }
+    if (cfg.ne <= 8) return launch_one<KH, KW, CI_T, 2, 8>(a, grid, block, cfg.lds, stream);
+    return launch_one<KH, KW, CI_T, 2, 16>(a, grid, block, cfg.lds, stream);
+}
 
 int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W,
                 hipStream_t stream) {
     NND_REQUIRE(io.src0.C + io.src1.C == L.Cin, "conv: source channels %d+%d != Cin %d", io.src0.C, io.src1.C, L.Cin);
     NND_REQUIRE(io.src1.C == 0 || io.src0.C % L.CI_T == 0, "conv: first source (%d ch) must be a multiple of %d", io.src0.C, L.CI_T);
-    NND_REQUIRE((long)L.Cin * H * W < (1L << 31), "conv: plane offsets exceed 32 bits");
+    NND_REQUIRE((long)(L.Cin + 2 * L.CI_T) * H * W < (1L << 31), "conv: plane offsets exceed 32 bits");
     TileCfg cfg;
     NND_REQUIRE(pick_tile(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv: no tile configuration for %dx%d Cin=%d", L.KH, L.KW, L.Cin);
     ConvArgs a;
@@ -350,26 +387,28 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
-    a.log2_sc = cfg.log2_sc; a.tiles_x = cfg.tiles_x; a.S = cfg.S; a.wco = cfg.wco; a.ks = cfg.ks;
+    a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks;
+    a.npos = cfg.npos; a.ngroups = cfg.ngroups;
     a.scale = io.scale;
-    const size_t lds = cfg.lds;
     dim3 grid(cfg.tiles_x * cfg.tiles_y, cdiv(L.ncb, cfg.wco), B), block(64 * cfg.wco * cfg.ks);
-    if (getenv("NND_CONV_VERBOSE"))
-        fprintf(stderr, "[nnd] conv %dx%d Cin=%d Cout=%d: tile 2^%d cols, P=%d, wco=%d, ks=%d, grid %ux%ux%u, lds %zu B\n", L.KH,
-                L.KW, L.Cin, L.Cout, cfg.log2_sc, cfg.P, cfg.wco, cfg.ks, grid.x, grid.y, grid.z, lds);
-    bool launched = false;
-    NND_CONV_CASE(1, 1, 8)
-    NND_CONV_CASE(1, 1, 32)
-    NND_CONV_CASE(3, 3, 8)
-    NND_CONV_CASE(1, 5, 8)
-    NND_CONV_CASE(5, 1, 8)
-    if (!launched) {
-        set_error("conv %dx%d CI_T=%d not instantiated", L.KH, L.KW, L.CI_T);
-        return NND_ERR_UNSUPPORTED;
-    }
+    static const bool verbose = getenv("NND_CONV_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[nnd] conv %dx%d Cin=%d Cout=%d CI_T=%d: P=%d, wco=%d, ks=%d, ne=%d, grid %ux%ux%u, lds %zu B\n",
+                L.KH, L.KW, L.Cin, L.Cout, L.CI_T, cfg.P, cfg.wco, cfg.ks, cfg.ne, grid.x, grid.y, grid.z, cfg.lds);
+    int rc = NND_ERR_UNSUPPORTED;
+    if (L.KH == 1 && L.KW == 1 && L.CI_T == 128) rc = launch_shape<1, 1, 128>(a, cfg, grid, block, stream);
+    else if (L.KH == 1 && L.KW == 1 && L.CI_T == 32) rc = launch_shape<1, 1, 32>(a, cfg, grid, block, stream);
+    else if (L.KH == 3 && L.KW == 3 && L.CI_T == 32) rc = launch_shape<3, 3, 32>(a, cfg, grid, block, stream);
+    else if (L.KH == 1 && L.KW == 5 && L.CI_T == 32) rc = launch_shape<1, 5, 32>(a, cfg, grid, block, stream);
+    else if (L.KH == 5 && L.KW == 1 && L.CI_T == 32) rc = launch_shape<5, 1, 32>(a, cfg, grid, block, stream);
+    else set_error("conv %dx%d CI_T=%d not instantiated", L.KH, L.KW, L.CI_T);
+    if (rc != NND_OK) return rc;
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
+
+// input channels per K-chunk for a layer shape (the host packer and the kernels must agree)
+int conv_ci_t(int KH, int KW, int Cin) { return (KH == 1 && KW == 1 && Cin >= 128) ? 128 : 32; }
 
 void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const float* const* bvec,
                const int* cout, float* blob) {
@@ -378,6 +417,8 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
     float* bp = blob + L.b_off;
     memset(wp, 0, sizeof(float) * L.w_floats());
     memset(bp, 0, sizeof(float) * L.b_floats());
+    // blob order: [cb][chunk][tap][q][lane][j]; lane = h2*32 + (co%32); channel in chunk = (q*4+j)*2 + h2.
+    // For CI_T >= 32 the kernel walks (tap, 32-channel group) steps, i.e. q = g*4 + q' — the same linear order.
     int co0 = 0;
     for (int part = 0; part < nparts; ++part) {
         for (int col = 0; col < cout[part]; ++col) {

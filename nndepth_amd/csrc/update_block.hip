@@ -33,8 +33,9 @@ struct Plan {
     int64_t total;
 };
 
-static ConvLayer mk(int KH, int KW, int Cin, int Cout, int CI_T, int64_t* off) {
+static ConvLayer mk(int KH, int KW, int Cin, int Cout, int64_t* off) {
     ConvLayer l;
+    const int CI_T = conv_ci_t(KH, KW, Cin);
     l.KH = KH; l.KW = KW; l.Cin = Cin; l.Cout = Cout; l.CI_T = CI_T;
     l.nchunks = cdiv(Cin, CI_T);
     l.ncb = cdiv(Cout, 32);
@@ -56,26 +57,26 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->sep = d->gru_kind == 0;
     int64_t off = 0;
     const int gin = hid + ctx + hid;
-    p->L[C_C1] = mk(1, 1, cp, 256, cp >= 64 ? 32 : 8, &off);
-    p->L[C_C2] = mk(3, 3, 256, 192, 8, &off);
+    p->L[C_C1] = mk(1, 1, cp, 256, &off);
+    p->L[C_C2] = mk(3, 3, 256, 192, &off);
     p->f1_w = off; off += (int64_t)128 * fc * 49;
     p->f1_b = off; off += 128;
-    p->L[C_F2] = mk(3, 3, 128, 64, 8, &off);
-    p->L[C_CV] = mk(3, 3, 256, hid - fc, 8, &off);
+    p->L[C_F2] = mk(3, 3, 128, 64, &off);
+    p->L[C_CV] = mk(3, 3, 256, hid - fc, &off);
     if (p->sep) {
-        p->L[C_ZR1] = mk(1, 5, gin, 2 * hid, 8, &off);
-        p->L[C_Q1] = mk(1, 5, gin, hid, 8, &off);
-        p->L[C_ZR2] = mk(5, 1, gin, 2 * hid, 8, &off);
-        p->L[C_Q2] = mk(5, 1, gin, hid, 8, &off);
+        p->L[C_ZR1] = mk(1, 5, gin, 2 * hid, &off);
+        p->L[C_Q1] = mk(1, 5, gin, hid, &off);
+        p->L[C_ZR2] = mk(5, 1, gin, 2 * hid, &off);
+        p->L[C_Q2] = mk(5, 1, gin, hid, &off);
     } else {
-        p->L[C_ZR1] = mk(3, 3, gin, 2 * hid, 8, &off);
-        p->L[C_Q1] = mk(3, 3, gin, hid, 8, &off);
+        p->L[C_ZR1] = mk(3, 3, gin, 2 * hid, &off);
+        p->L[C_Q1] = mk(3, 3, gin, hid, &off);
         p->L[C_ZR2] = p->L[C_ZR1];
         p->L[C_Q2] = p->L[C_Q1];
     }
-    p->L[C_FM1] = mk(3, 3, hid, 3 * hid, 8, &off);
-    p->L[C_FC2] = mk(3, 3, hid, fc, 8, &off);
-    p->L[C_M2] = mk(1, 1, 2 * hid, mc, 32, &off);
+    p->L[C_FM1] = mk(3, 3, hid, 3 * hid, &off);
+    p->L[C_FC2] = mk(3, 3, hid, fc, &off);
+    p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off);
     p->total = off;
     return NND_OK;
 }
@@ -424,7 +425,7 @@ static int conv2d_layer(int Cout, int Cin, int KH, int KW, ConvLayer* L, int64_t
     NND_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 1 && KW == 5) || (KH == 5 && KW == 1),
                 "conv2d: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", KH, KW);
     int64_t off = 0;
-    *L = mk(KH, KW, Cin, Cout, (KH == 1 && KW == 1 && Cin >= 64) ? 32 : 8, &off);
+    *L = mk(KH, KW, Cin, Cout, &off);
     if (total) *total = off;
     return NND_OK;
 }
@@ -503,4 +504,48 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, flo
     (void)hipEventDestroy(e1);
     return rc;
 }
+}
+
+// ------------------------------------------------------------------------------ MFMA peak probe
+// Dependent chains of v_mfma_f32_32x32x2_f32 with no memory traffic: what the chip sustains on this box at
+// `waves_per_simd` resident waves (clock under load included).  Diagnostic used to put the conv numbers in
+// context; not on any product path.
+namespace nnd {
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) mfma_probe_kernel(float* out, int iters, float seed) {
+    f32x16_ acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    float av = seed + threadIdx.x * 1e-3f, bv = seed * 0.5f + threadIdx.x * 2e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc1, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    if (s == 12345.678f) out[0] = s;  // keep the chain live without a real store
+}
+}  // namespace nnd
+
+extern "C" int nnd_profile_mfma_peak(int waves_per_simd, int iters, void* stream, float* scratch_dev, float* tflops_out) {
+    NND_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0 && scratch_dev && tflops_out, "mfma_peak: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    NND_HIP_CHECK(hipEventCreate(&e0));
+    NND_HIP_CHECK(hipEventCreate(&e1));
+    dim3 grid(256 * waves_per_simd), block(256);
+    hipLaunchKernelGGL(nnd::mfma_probe_kernel, grid, block, 0, s, scratch_dev, 16, 1.0f);
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(nnd::mfma_probe_kernel, grid, block, 0, s, scratch_dev, iters, 1.0f);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    double flops = 2.0 * 32 * 32 * 2 * 16.0 * iters * 4.0 * 256.0 * waves_per_simd;
+    *tflops_out = (float)(flops / (ms * 1e-3) / 1e12);
+    return NND_OK;
 }

@@ -14,3 +14,11 @@ ws.normal_()
 for i, nm in enumerate(eng.conv_names()):
     ms, fl = eng.profile_conv(i, 1, 68, 120, reps, "cuda:0")
     print(f"{i:2d} {nm:26s} {ms*1e3:8.1f} us {fl/ms/1e9:6.1f} TF")
+
+import ctypes as C
+from nndepth_amd._lib import lib, check
+scr = torch.zeros(16, device="cuda:0")
+for w in (1, 2, 4):
+    tf = C.c_float()
+    check(lib.nnd_profile_mfma_peak(w, 20000, None, C.c_void_p(scr.data_ptr()), C.byref(tf)))
+    print(f"mfma peak probe, {w} waves/SIMD: {tf.value:.1f} TFLOP/s")
