@@ -34,6 +34,10 @@ namespace nnd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef NND_INTERLEAVE
+#define NND_INTERLEAVE 0
+#endif
+
 struct ConvArgs {
     const float* src0;
     const float* src1;
@@ -198,7 +202,6 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             } else {
                 load_a(an, wn, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             if (mine) {
 #pragma unroll
                 for (int q = 0; q < AQ; ++q) {
@@ -210,6 +213,17 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
                             acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[j], bq[s & 1][(q * 4 + j) * P + pp], acc[pp], 0, 0, 0);
                 }
             }
+#if NND_INTERLEAVE
+            // issue pattern: after every MFMA (64 cycles in the matrix pipe) one LDS read / weight load of the
+            // NEXT step and its address arithmetic, so the fetch phase hides under the MFMAs of this step
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+                if (i < AQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);  // VALU / SALU
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_x(K + 1);
@@ -294,13 +308,14 @@ struct TileCfg {
 // SIMDs of the chip, so the busiest SIMD runs ceil(waves/1024) * unit (quantisation is what matters at
 // batch 1: 68x120 = 255 tiles of 4x8 pixels).
 static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, TileCfg* out) {
-    int force_p = -1, force_ks = -1;
-    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d", &force_p, &force_ks);
+    int force_p = -1, force_ks = -1, force_wco = -1;
+    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &force_p, &force_ks, &force_wco);
     double best = 1e30;
     bool found = false;
     for (int ks : {1, 2})
     for (int wco : {4, 3, 2, 1}) {
         if (force_ks > 0 && ks != force_ks) continue;
+        if (force_wco > 0 && wco != force_wco) continue;
         if (ks > L.nchunks || wco * ks > 8) continue;
         if (c1 > 0 && c0 % (ks * L.CI_T) != 0) continue;
         if (wco > 1 && cdiv(L.ncb, wco) * wco >= L.ncb + wco) continue;  // a whole workgroup of idle waves

@@ -1,0 +1,128 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/nndepth_amd.h declares,
+its host-side functions (layout, packing, sizing, argument validation) behave, and the Python seams
+refuse to compute anywhere but on the HIP device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "nndepth_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nnd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nndepth_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    raw = C.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/nndepth_amd.h but not exported"
+    assert set(_lib.SIGNATURES) == set(syms), "ctypes table and header out of sync"
+    assert _lib.lib.nnd_version() == 100
+    assert _lib.lib.nnd_device_count() >= 0  # must not raise / abort on a CPU-only host
+
+
+def test_pyramid_layout_host():
+    from nndepth_amd import ops
+    offs, widths, total = ops.pyramid_layout(2, 5, 21, 4)
+    assert widths == [21, 10, 5, 2, 1]  # floor on odd widths; 5 levels stored, 4 read (Q1)
+    rows = 2 * 5 * 21
+    assert offs == [0, rows * 21, rows * 31, rows * 36, rows * 38] and total == rows * 39
+    from nndepth_amd._lib import NndError
+    with pytest.raises(NndError):
+        ops.pyramid_layout(0, 5, 21, 4)
+
+
+def _unpack(blob, Cout, Cin, KH, KW):
+    """Inverse of the documented A-fragment order [cb][chunk][tap][q][lane][j]."""
+    NT = KH * KW
+    CI_T = 128 if (KH == 1 and KW == 1 and Cin >= 128) else 32
+    NQ, nch, ncb = CI_T // 8, -(-Cin // CI_T), -(-Cout // 32)
+    n = ncb * nch * NT * NQ * 256
+    Wp = blob[:n].reshape(ncb, nch, NT, NQ, 2, 32, 4)  # cb, chunk, tap, q, h2, i, j
+    rec = np.zeros((ncb, 32, nch, CI_T, NT), np.float32)
+    for q in range(NQ):
+        for j in range(4):
+            for h2 in range(2):
+                rec[:, :, :, (q * 4 + j) * 2 + h2, :] = Wp[:, :, :, q, h2, :, j].transpose(0, 3, 1, 2)
+    return rec.reshape(ncb * 32, nch * CI_T, NT), blob[n:n + ncb * 32]
+
+
+@pytest.mark.parametrize("shape", [(192, 256, 3, 3), (127, 256, 3, 3), (576, 256, 1, 1), (256, 36, 1, 1),
+                                   (256, 320, 1, 5), (128, 320, 5, 1), (1, 128, 3, 3)])
+def test_conv2d_pack_host(shape):
+    from nndepth_amd import ops
+    Cout, Cin, KH, KW = shape
+    g = torch.Generator().manual_seed(0)
+    w, b = torch.randn(shape, generator=g), torch.randn(Cout, generator=g)
+    conv = ops.Conv2d(w, b, device=None)  # host-only: pack, never touches a GPU
+    rec, bias = _unpack(conv.packed_host.numpy(), Cout, Cin, KH, KW)
+    assert np.array_equal(rec[:Cout, :Cin], w.numpy().reshape(Cout, Cin, KH * KW))
+    assert not rec[Cout:].any() and not rec[:, Cin:].any(), "padding must be zero"
+    assert np.array_equal(bias[:Cout], b.numpy()) and not bias[Cout:].any()
+
+
+def test_update_block_pack_and_sizes_host():
+    from nndepth_amd import ops, weightgen
+    from nndepth_amd._lib import lib, NndError, UpdateBlockDesc
+    from oracle import torch_ref as R
+    eng = ops.UpdateBlockEngine(128, 64, 36, 1, 576, "sep_conv")
+    assert lib.nnd_update_block_num_tensors(C.byref(eng.desc)) == 30 == len(ops.update_block_keys("sep_conv"))
+    assert len(ops.update_block_keys("conv_gru")) == 24
+    sd = weightgen.fill_state_dict(R.update_block_spec("u", 128, 36, 64, 1, 8))
+    blob = eng.pack_host(sd, "u.")
+    assert blob.numel() == eng.packed_floats and torch.isfinite(blob).all()
+    # first layer of the blob is encoder.convc1 (1x1, 36 -> 256, CI_T 32)
+    rec, bias = _unpack(blob.numpy(), 256, 36, 1, 1)
+    assert np.array_equal(rec[:256, :36, 0], sd["u.encoder.convc1.weight"].numpy()[:, :, 0, 0])
+    assert np.array_equal(bias[:256], sd["u.encoder.convc1.bias"].numpy())
+    assert lib.nnd_update_block_workspace_floats(C.byref(eng.desc), 1, 68, 120) > 2000 * 68 * 120
+    bad = UpdateBlockDesc(100, 64, 36, 1, 576, 0)  # hidden_dim not a multiple of 32
+    assert lib.nnd_update_block_packed_floats(C.byref(bad)) < 0
+    assert b"hidden_dim" in lib.nnd_last_error()
+    with pytest.raises(NndError):
+        ops.UpdateBlockEngine(128, 64, 36, 3, 576)  # flow_channels must be 1 or 2
+
+
+def test_null_and_shape_errors_do_not_crash():
+    from nndepth_amd._lib import lib
+    assert lib.nnd_corr1d_build(None, None, None, 1, 8, 4, 8, 4, None) == -1
+    assert b"null" in lib.nnd_last_error()
+    assert lib.nnd_convex_upsample(None, None, None, 1, 1, 4, 8, 8, None) == -1
+    assert lib.nnd_conv2d_packed_floats(8, 8, 7, 7) < 0  # kernel size not built
+
+
+def test_seams_refuse_cpu_tensors():
+    """No silent CPU/eager fallback: every op raises on non-HIP tensors."""
+    from nndepth_amd import ops
+    from nndepth_amd._lib import NndError
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.cost_volume import CorrBlock1D
+    from nndepth_amd.upsample import convex_upsample
+    with pytest.raises(NndError):
+        CorrBlock1D(torch.zeros(1, 8, 4, 16), torch.zeros(1, 8, 4, 16), 4, 4)
+    with pytest.raises(NndError):
+        convex_upsample(torch.zeros(1, 1, 4, 8), torch.zeros(1, 576, 4, 8), 8)
+    ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8)
+    with pytest.raises(NndError):
+        ub(torch.zeros(1, 128, 4, 8), torch.zeros(1, 64, 4, 8), torch.zeros(1, 36, 4, 8), torch.zeros(1, 1, 4, 8))
+    with pytest.raises(NndError):
+        ops.corr1d_lookup(torch.zeros(10), torch.zeros(1, 1, 2, 2), 4, 4)
+
+
+def test_update_block_state_dict_keys_match_reference_order():
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd import ops
+    ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8)
+    assert list(ub.state_dict().keys()) == ops.update_block_keys("sep_conv")
+    ub2 = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=128, gru="conv_gru", flow_channel=2)
+    assert list(ub2.state_dict().keys()) == ops.update_block_keys("conv_gru")
+    assert tuple(ub2.state_dict()["mask.2.weight"].shape) == (576, 256, 1, 1)

@@ -1,0 +1,60 @@
+"""CPU, world_size 2, gloo: the batch-parallel sharding + disparity all-gather used by bench.py --gpus N
+(nndepth_amd/parallel.py).  The GPU path uses the same code with backend "nccl" (= RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nndepth_amd import parallel
+    r, w, _ = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    pairs = list(parallel.shard_range(5, r, w))  # 5 pairs over 2 ranks -> 3 + 2
+    # each rank "computes" a disparity map per pair (value = pair id) at a small shape
+    local = torch.stack([torch.full((1, 4, 6), float(p)) for p in pairs[:2]])  # equal count per rank for gather
+    out = parallel.gather_disparity(local)
+    t = parallel.max_over_ranks(1.0 + rank, "cpu")
+    parallel.barrier()
+    q.put((rank, pairs, out[:, 0, 0, 0].tolist(), t))
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    from nndepth_amd import parallel
+    assert [list(parallel.shard_range(10, r, 4)) for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    assert list(parallel.shard_range(3, 0, 1)) == [0, 1, 2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4]
+    # all-gather returns rank-ordered concatenation on every rank
+    assert res[0][2] == res[1][2] == [0.0, 1.0, 3.0, 4.0]
+    assert res[0][3] == res[1][3] == 2.0  # max over ranks
+
+
+def test_single_process_is_a_noop():
+    from nndepth_amd import parallel
+    x = torch.arange(6.0).view(1, 1, 2, 3)
+    assert parallel.gather_disparity(x) is x
+    assert parallel.max_over_ranks(3.5, "cpu") == 3.5

@@ -1,0 +1,78 @@
+"""CPU: the oracle (oracle/torch_ref.py) against the golden vectors produced by the imported reference
+(oracle/make_golden.py).  This is what pins the oracle; the GPU tests then compare HIP vs oracle/golden."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import t
+from oracle import torch_ref as R
+
+
+@pytest.mark.parametrize("name", ["c16_w21", "c256_w40", "c32_w39"])
+def test_corr1d_build_and_lookup(gold, name):
+    g = gold("corr1d.npz")
+    f1, f2, coords = (t(g[f"{name}_{k}"]) for k in ("f1", "f2", "coords"))
+    pyr = R.corr1d_build(f1, f2, 4)
+    assert len(pyr) == 5  # one level more than is ever read
+    for i, p in enumerate(pyr):
+        assert np.array_equal(p[:, 0].numpy(), g[f"{name}_pyr{i}"]), f"level {i}"
+    out = R.corr1d_lookup(pyr, coords, 4, 4)
+    assert np.array_equal(out.numpy(), g[f"{name}_out"])
+
+
+def test_linear_sampler_border_clamp():
+    """Q2: coordinates outside [0, w-1] clamp to the border (not zero padding); integers return the sample."""
+    row = torch.arange(10.0)[None] * 2.0
+    x = torch.tensor([[-5.0, 0.0, 3.0, 3.5, 9.0, 20.0]])
+    got = R.linear_sampler(row, x)
+    assert torch.allclose(got, torch.tensor([[0.0, 0.0, 6.0, 7.0, 18.0, 18.0]]), atol=1e-5)
+
+
+@pytest.mark.parametrize("name,hid,ctx,cp,fc,sps", [
+    ("raft_h128_c64", 128, 64, 36, 1, 8), ("raft_h128_c128", 128, 128, 36, 1, 8),
+    ("cre_h128_c128_f2", 128, 128, 36, 2, 8), ("igev_h64_c64_cp576", 64, 64, 576, 1, 4)])
+def test_update_block(gold, name, hid, ctx, cp, fc, sps):
+    from nndepth_amd import weightgen
+    g = gold("update_block.npz")
+    sd = weightgen.fill_state_dict(R.update_block_spec("ub." + name, hid, cp, ctx, fc, sps))
+    net, inp, corr, flow = (t(g[f"{name}_{k}"]) for k in ("net", "inp", "corr", "flow"))
+    with torch.no_grad():
+        n, m, d = R.update_block(sd, "ub." + name, net, inp, corr, flow)
+        mf = R.motion_encoder(sd, f"ub.{name}.encoder", flow, corr)
+    # bit-exact in the container that made the goldens; allow last-bit drift across CPU ISAs (oneDNN kernels)
+    for got, key in ((n, "net_out"), (m, "mask_out"), (d, "delta_out"), (mf, "motion")):
+        assert np.abs(got.numpy() - g[f"{name}_{key}"]).max() <= 2e-5, key
+
+
+@pytest.mark.parametrize("name,rate", [("r8_c1", 8), ("r4_c1", 4), ("r8_c2", 8)])
+def test_convex_upsample(gold, name, rate):
+    g = gold("upsample.npz")
+    out = R.convex_upsample(t(g[name + "_flow"]), t(g[name + "_mask"]), rate)
+    assert np.abs(out.numpy() - g[name + "_out"]).max() <= 1e-5
+
+
+def test_forward_small(gold, raft_sd):
+    from nndepth_amd import weightgen
+    g = gold("forward_small.npz")
+    f1, f2 = weightgen.synthetic_frames(0, 1, 96, 160)
+    with torch.no_grad():
+        ups = R.raft_stereo_forward(raft_sd, f1, f2, 6)
+    for i in range(6):
+        assert np.abs(ups[i].numpy() - g["up_disp"][i]).max() <= 1e-4, i
+
+
+def test_spec_matches_module_and_weightgen_is_deterministic(raft_sd):
+    """state_dict keys/shapes of the drop-in model == the spec verified against the reference;
+    the generator is a pure function of (key, shape)."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    m = BaseRAFTStereo(iters=1, context_dim=64)
+    sd = m.state_dict()
+    spec = R.raft_stereo_spec()
+    assert list(sd.keys()) == [k for k, _ in spec]
+    assert all(tuple(sd[k].shape) == tuple(s) for k, s in spec)
+    again = weightgen.fill_state_dict(spec)
+    assert all(torch.equal(raft_sd[k], again[k]) for k in raft_sd)
+    # the aliased shortcut norm carries identical values under both names (residual_block.py:51)
+    assert torch.equal(raft_sd["fnet.layer1.0.norm3.weight"], raft_sd["fnet.layer1.0.downsample.1.weight"])
+    m.load_state_dict(raft_sd, strict=True)
