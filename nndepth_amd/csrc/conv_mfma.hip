@@ -182,48 +182,49 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
         const bool mine = K * ks + kj < nchunks;
         const float* xb = lds + (K & 1) * (SCH * PATCH) + lane_base;
         float bq[2][NB];
-        auto read_step = [&](int s, float* dst) {
-            const int t = s / NGRP, g = s % NGRP;
+        // B operands of step s, group g (8 LDS reads): operand index i = pair*P + pp
+        auto read_group = [&](int s, int g, float* dst) {
+            const int t = s / NGRP, grp = s % NGRP;
             const int dy = t / KW, dx = t % KW;
 #pragma unroll
-            for (int pair = 0; pair < SG / 2; ++pair)
-#pragma unroll
-                for (int pp = 0; pp < P; ++pp)
-                    dst[pair * P + pp] = xb[(g * SG + pair * 2) * PATCH + dy * S + dx + pp * SC];
+            for (int i = g * 8; i < g * 8 + 8; ++i) {
+                const int pair = i / P, pp = i % P;
+                dst[i] = xb[(grp * SG + pair * 2) * PATCH + dy * S + dx + pp * SC];
+            }
         };
-        read_step(0, bq[0]);
+        constexpr int NRG = NB / 8;  // read groups per step
+#pragma unroll
+        for (int g = 0; g < NRG; ++g) read_group(0, g, bq[0]);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float4* ac = abuf[(par + s) & 1];
             float4* an = abuf[(par + s + 1) & 1];
-            if (s + 1 < NS) {
-                load_a(an, wc, s + 1);
-                read_step(s + 1, bq[(s + 1) & 1]);
-            } else {
-                load_a(an, wn, 0);
-            }
-            if (mine) {
-#pragma unroll
-                for (int q = 0; q < AQ; ++q) {
-                    const float avs[4] = {ac[q].x, ac[q].y, ac[q].z, ac[q].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int pp = 0; pp < P; ++pp)
-                            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(avs[j], bq[s & 1][(q * 4 + j) * P + pp], acc[pp], 0, 0, 0);
-                }
-            }
-#if NND_INTERLEAVE
-            // issue pattern: after every MFMA (64 cycles in the matrix pipe) one LDS read / weight load of the
-            // NEXT step and its address arithmetic, so the fetch phase hides under the MFMAs of this step
+            if (s + 1 < NS) load_a(an, wc, s + 1);
+            else load_a(an, wn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // MFMAs of step s with the LDS reads of step s+1 slotted in 8 at a time, late enough that at most 8
+            // reads are in flight whenever an MFMA that depends on older reads issues (lgkmcnt is in-order and
+            // saturates at 15: a burst of 16 reads in front of the MFMAs would stall each step ~100 cycles)
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-                if (i < AQ) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-                __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);  // VALU / SALU
+                if (s + 1 < NS) {
+#pragma unroll
+                    for (int g = 0; g < NRG; ++g) {
+                        const int at = (8 * (g + 1) < NB - 4) ? 8 * (g + 1) : NB - 4 - 4 * (NRG - 1 - g);
+                        if (i == at) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            read_group(s + 1, g, bq[(s + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                if (mine) {
+                    const int pair = i / P, pp = i % P;
+                    const float4 av = ac[pair / 4];
+                    const float a_s = (pair % 4 == 0) ? av.x : (pair % 4 == 1) ? av.y : (pair % 4 == 2) ? av.z : av.w;
+                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, bq[s & 1][i], acc[pp], 0, 0, 0);
+                }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) store_x(K + 1);
