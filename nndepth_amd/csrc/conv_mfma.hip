@@ -38,6 +38,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NND_INTERLEAVE 0
 #endif
 
+#ifndef NND_SC
+#define NND_SC 8
+#endif
+// LDS row stride: smallest odd multiple of SC that holds PC columns (lanes (r, c) then hit 32 distinct banks)
+__host__ __device__ constexpr int patch_stride(int PC, int SC) {
+    int s = SC;
+    while (s < PC) s += 2 * SC;
+    return s;
+}
+
 struct ConvArgs {
     const float* src0;
     const float* src1;
@@ -56,7 +66,30 @@ struct ConvArgs {
     float scale;
 };
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// exp(x) to ~1 ulp without libm's special-case branches: x*log2(e) is split into the rounded product t and its
+// exact residual r (fma), so exp(x) = exp2(t) * 2^r ~= exp2(t) * (1 + r*ln2); v_exp_f32 itself is ~1 ulp.
+__device__ __forceinline__ float exp_acc(float x) {
+    const float L2E = 1.44269504088896341f;
+    x = fminf(fmaxf(x, -87.0f), 88.0f);
+    const float t = x * L2E;
+    const float r = fmaf(x, L2E, -t) + x * 1.92596299e-8f;  // + x * (log2e - (float)log2e)
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.693147180559945f, e);
+}
+// 1/d with one Newton step on v_rcp_f32 (<= 1 ulp)
+__device__ __forceinline__ float rcp_acc(float d) {
+    float y = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, y, 1.0f), y, y);
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return rcp_acc(1.0f + exp_acc(-v)); }
+// tanh(x) = sign(x) * (1 - 2/(exp(2|x|) + 1)); for |x| < 0.04 the odd series avoids the cancellation
+__device__ __forceinline__ float tanhf_(float v) {
+    const float ax = fabsf(v);
+    const float big = 1.0f - 2.0f * rcp_acc(exp_acc(2.0f * ax) + 1.0f);
+    const float x2 = ax * ax;
+    const float small = ax * fmaf(x2, fmaf(x2, 0.133333333f, -0.333333333f), 1.0f);
+    return copysignf(ax < 0.04f ? small : big, v);
+}
 
 // NE: patch elements staged per thread per super-chunk (the thread owns one patch position and NE channels)
 template <int KH, int KW, int CI_T, int P, int NE>
@@ -75,8 +108,8 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     const int wco = a.wco, ks = a.ks;
     const int cbi = wave % wco, kj = wave / wco;
     const int h2 = lane >> 5, l31 = lane & 31;
-    constexpr int SC = 8, SR = 4;  // MFMA column block = 4 rows x 8 cols of pixels
-    const int r = l31 >> 3, c = l31 & 7;
+    constexpr int SC = NND_SC, SR = 32 / NND_SC;  // MFMA column block = SR rows x SC cols of pixels
+    const int r = l31 / SC, c = l31 % SC;
     const int tx0 = (blockIdx.x % a.tiles_x) * (P * SC);
     const int ty0 = (blockIdx.x / a.tiles_x) * SR;
     const int cb = blockIdx.y * wco + cbi;
@@ -87,7 +120,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     // LDS patch geometry is compile-time so every B-operand read is base + immediate offset.
     // Row stride S is an odd multiple of SC: lanes (r, c) then hit 32 distinct banks.
     constexpr int PR = SR + KH - 1, PC = P * SC + KW - 1;
-    constexpr int S = PC <= 8 ? 8 : (PC <= 24 ? 24 : 40), PATCH = PR * S;
+    constexpr int S = patch_stride(PC, SC), PATCH = PR * S;
     const int SCH = ks * CI_T;  // channels per super-chunk
 
     // ---- staging role of this thread: patch position `pos`, channels cg, cg+ngroups, ... (NE of them)
@@ -176,7 +209,9 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     auto chunk = [&](int K, auto par_c) {
         constexpr int par = decltype(par_c)::value;
         const bool more = (K + 1 < nsuper);
+#ifndef NND_DBG_NO_STAGE
         if (more) load_x(K + 1);
+#endif
         const float4* wc = a_ptr(K);
         const float4* wn = a_ptr(more ? K + 1 : K);
         const bool mine = K * ks + kj < nchunks;
@@ -199,8 +234,12 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
         for (int s = 0; s < NS; ++s) {
             float4* ac = abuf[(par + s) & 1];
             float4* an = abuf[(par + s + 1) & 1];
+#ifndef NND_DBG_NO_ALOAD
             if (s + 1 < NS) load_a(an, wc, s + 1);
             else load_a(an, wn, 0);
+#else
+            for (int q = 0; q < AQ; ++q) an[q] = ac[q];
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // MFMAs of step s with the LDS reads of step s+1 slotted in 8 at a time, late enough that at most 8
             // reads are in flight whenever an MFMA that depends on older reads issues (lgkmcnt is in-order and
@@ -227,8 +266,12 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef NND_DBG_NO_STAGE
         if (more) store_x(K + 1);
+#endif
+#ifndef NND_DBG_NO_BARRIER
         __syncthreads();
+#endif
     };
     if constexpr (NS % 2 == 0) {
         for (int K = 0; K < nsuper; ++K) chunk(K, std::integral_constant<int, 0>{});
@@ -239,41 +282,75 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
         }
     }
 
-    // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier)
+    // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier).
+    // Every K-slice wave publishes its partial tile; slice kj then owns registers [kj*16/ks, (kj+1)*16/ks) of the
+    // tile for the epilogue, so the gate math / stores of a tile are spread over all ks waves.
+    constexpr int TS = P * 1024;  // floats per partial tile in LDS
     if (ks > 1) {
-        if (kj > 0 && active) {
-            float* red = lds + (size_t)((cbi * (ks - 1) + (kj - 1)) * P) * 1024 + lane;
+        if (active) {
+            float* red = lds + (size_t)(cbi * ks + kj) * TS + lane;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) red[pp * 1024 + reg * 64] = acc[pp][reg];
         }
         __syncthreads();
-        if (kj == 0 && active) {
-            for (int j = 1; j < ks; ++j) {
-                const float* red = lds + (size_t)((cbi * (ks - 1) + (j - 1)) * P) * 1024 + lane;
+    }
+    if (!active) return;
+    const int nreg = 16 / ks, reg0 = kj * nreg;  // ks is 1 or 2 (or 4): this wave's share of the tile
+    if (ks > 1) {
+        const float* red = lds + (size_t)(cbi * ks) * TS + lane;
 #pragma unroll
-                for (int pp = 0; pp < P; ++pp)
+        for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) acc[pp][reg] += red[pp * 1024 + reg * 64];
+            for (int reg = 0; reg < 16; ++reg) {
+                if (reg < reg0 || reg >= reg0 + nreg) continue;
+                float sum = red[pp * 1024 + reg * 64];
+                for (int j = 1; j < ks; ++j) sum += red[(size_t)j * TS + pp * 1024 + reg * 64];
+                acc[pp][reg] = sum;
             }
-        }
     }
 
-    // ---- epilogue: lane holds pixel (y, x_pp) and 16 output channels
-    if (!active || kj != 0) return;
+    // ---- epilogue: lane holds pixel (y, x_pp) and 16 output channels.  All loads (bias, h, z) are issued
+    // before any store: out0 may alias aux0 (GRU blend in place), which would otherwise serialise load/store.
     const int y = ty0 + r;
     const int epi = a.epi;
+    float bias_r[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+        bias_r[reg] = (reg >= reg0 && reg < reg0 + nreg && co < a.Cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) {
         const int x = tx0 + pp * SC + c;
-        if (y >= H || x >= W) continue;
-        const long pix = (long)y * W + x;
+        const bool pix_ok = (y < H && x < W);
+        const long pix = pix_ok ? (long)y * W + x : 0;
+        float h_r[16], z_r[16];
+        if (epi == EPI_GRU_ZR || epi == EPI_GRU_Q) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
+                h_r[reg] = 0.f;
+                z_r[reg] = 0.f;
+                if (epi == EPI_GRU_Q) {
+                    if (ok) {
+                        h_r[reg] = a.aux0[b * a.abs0 + co * HW + pix];
+                        z_r[reg] = a.aux1[b * a.abs1 + co * HW + pix];
+                    }
+                } else if (ok && co >= a.hidden) {
+                    h_r[reg] = a.aux0[b * a.abs0 + (co - a.hidden) * HW + pix];
+                }
+            }
+        }
+        if (!pix_ok) continue;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
+            if (reg < reg0 || reg >= reg0 + nreg) continue;
             const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
             if (co >= a.Cout) continue;
-            float v = acc[pp][reg] + a.bias[co];
+            const float v = acc[pp][reg] + bias_r[reg];
             if (epi == EPI_RELU) {
                 a.out0[b * a.obs0 + co * HW + pix] = fmaxf(v, 0.f);
             } else if (epi == EPI_LINEAR) {
@@ -281,18 +358,12 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             } else if (epi == EPI_SCALE) {
                 a.out0[b * a.obs0 + co * HW + pix] = a.scale * v;
             } else if (epi == EPI_GRU_ZR) {
-                float s = sigmoidf_(v);
-                if (co < a.hidden) {
-                    a.out0[b * a.obs0 + co * HW + pix] = s;
-                } else {
-                    int cc = co - a.hidden;
-                    a.out1[b * a.obs1 + cc * HW + pix] = s * a.aux0[b * a.abs0 + cc * HW + pix];
-                }
+                const float sg = sigmoidf_(v);
+                if (co < a.hidden) a.out0[b * a.obs0 + co * HW + pix] = sg;
+                else a.out1[b * a.obs1 + (co - a.hidden) * HW + pix] = sg * h_r[reg];
             } else {  // EPI_GRU_Q
-                float q = tanhf(v);
-                float hprev = a.aux0[b * a.abs0 + co * HW + pix];
-                float z = a.aux1[b * a.abs1 + co * HW + pix];
-                a.out0[b * a.obs0 + co * HW + pix] = (1.0f - z) * hprev + z * q;
+                const float q = tanhf_(v);
+                a.out0[b * a.obs0 + co * HW + pix] = (1.0f - z_r[reg]) * h_r[reg] + z_r[reg] * q;
             }
         }
     }
@@ -324,17 +395,17 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
         {
             for (int P : {1, 2}) {
                 if (force_p > 0 && P != force_p) continue;
-                const int SC = 8, SR = 4;
+                const int SC = NND_SC, SR = 32 / NND_SC;
                 int tx = cdiv(W, P * SC), ty = cdiv(H, SR);
                 int PR = SR + L.KH - 1, PC = P * SC + L.KW - 1;
-                int S = PC <= 8 ? 8 : (PC <= 24 ? 24 : 40);  // must match the kernel's constexpr
+                int S = patch_stride(PC, SC);
                 int npos = PR * PC;
                 if (npos > nthreads) continue;
                 int ngroups = nthreads / npos;
                 int ne = cdiv(ks * L.CI_T, ngroups);
                 if (ne > 16) continue;
                 size_t lds = ((size_t)2 * ks * L.CI_T * PR * S + 1) * sizeof(float);
-                size_t red = (size_t)wco * (ks - 1) * P * 1024 * sizeof(float);
+                size_t red = ks > 1 ? (size_t)wco * ks * P * 1024 * sizeof(float) : 0;
                 if (red > lds) lds = red;
                 if (lds > 160 * 1024) continue;
                 int occ = P == 1 ? 4 : 2;  // resident waves per SIMD the register budget allows

@@ -9,8 +9,9 @@
 // torch.cat is never materialised: tensors that the reference concatenates live side by side in one
 // workspace buffer (hx = [h | inp | motion | flow], cf = [cor | flo], fm = [flow_head.conv1 | mask.0]) and the
 // convolutions write straight into their channel slice.  convz/convr are packed as one 2*hidden-channel
-// conv whose epilogue emits z and r*h; convq's epilogue does the GRU blend in place; flow_head.conv1 and
-// mask.0 (same input) are packed as one 3*hidden-channel conv.
+// conv whose epilogue emits z and r*h; convq's epilogue does the GRU blend in place.  In the fused loop the
+// flow branch (convf1 -> convf2) and the mask branch (mask.0 -> mask.2 -> convex upsample, which only feeds the
+// output) run on two side streams beside the critical path (see Streams / run_iteration).
 #include "common.h"
 
 #include <cstdlib>
@@ -20,10 +21,10 @@
 namespace nnd {
 
 // ------------------------------------------------------------------------------------ plan
-enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1, C_Q1, C_ZR2, C_Q2, C_FM1, C_FC2, C_M2, C_COUNT };
+enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1, C_Q1, C_ZR2, C_Q2, C_FH1, C_M0, C_FC2, C_M2, C_COUNT };
 static const char* kConvNames[C_COUNT] = {"encoder.convc1",        "encoder.convc2", "encoder.convf2", "encoder.conv",
                                           "gru.convz1+convr1",     "gru.convq1",     "gru.convz2+convr2", "gru.convq2",
-                                          "flow_head.conv1+mask.0", "flow_head.conv2", "mask.2"};
+                                          "flow_head.conv1", "mask.0", "flow_head.conv2", "mask.2"};
 
 struct Plan {
     nnd_update_block_desc d;
@@ -74,7 +75,8 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
         p->L[C_ZR2] = p->L[C_ZR1];
         p->L[C_Q2] = p->L[C_Q1];
     }
-    p->L[C_FM1] = mk(3, 3, hid, 3 * hid, &off);
+    p->L[C_FH1] = mk(3, 3, hid, hid, &off);
+    p->L[C_M0] = mk(3, 3, hid, 2 * hid, &off);
     p->L[C_FC2] = mk(3, 3, hid, fc, &off);
     p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off);
     p->total = off;
@@ -212,7 +214,8 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.aux0 = act(w.hx, hxC * n, hid);
             io.aux1 = act(w.z, hid * n, hid);
             break;
-        case C_FM1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, 3 * hid); break;
+        case C_FH1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, hid); break;
+        case C_M0: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid); break;
         case C_FC2: io.src0 = act(w.fm, 3 * hid * n, hid); io.out0 = act(delta_dst, fc * n, fc); break;
         case C_M2:
             io.src0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
@@ -266,8 +269,30 @@ static int run_convf1(const Plan& p, const float* blob, const float* flow, int64
     return debug_sync("encoder.convf1", s);
 }
 
+// Side streams + events for the fused loop.  Created once per device on first use (the only mutable global
+// state of the library); all cross-stream edges are explicit events, the caller's stream is joined at the end.
+struct Streams {
+    hipStream_t a = nullptr, b = nullptr;  // a: flow branch, b: mask/upsample branch
+    hipEvent_t start = nullptr, f2 = nullptr, q2 = nullptr, m0 = nullptr, adv = nullptr, up = nullptr;
+    bool ok = false;
+};
+static Streams* side_streams() {
+    static Streams st[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Streams& s = st[dev];
+    if (!s.ok) {
+        if (hipStreamCreateWithFlags(&s.a, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&s.b, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (hipEvent_t* e : {&s.start, &s.f2, &s.q2, &s.m0, &s.adv, &s.up})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.ok = true;
+    }
+    return &s;
+}
+
 // One application of the update block on workspace state: expects h/inp/flow already in w.hx,
-// `flow` = (B,fc,H,W) dense.  Writes new h into w.hx[0:hid], delta, and (optionally) the mask.
+// `flow` = (B,fc,H,W) dense.  Writes new h into w.hx[0:hid], delta, and (optionally) the mask.  Single stream.
 static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr, const float* flow, float* mask_dst,
                       float* delta_dst, int B, int H, int W, hipStream_t s) {
     int rc;
@@ -283,9 +308,12 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
         NND_TRY(run_conv(p, blob, w, C_ZR2, corr, nullptr, nullptr, B, H, W, s));
         NND_TRY(run_conv(p, blob, w, C_Q2, corr, nullptr, nullptr, B, H, W, s));
     }
-    NND_TRY(run_conv(p, blob, w, C_FM1, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_FH1, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_FC2, corr, nullptr, delta_dst, B, H, W, s));
-    if (mask_dst) NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
+    if (mask_dst) {
+        NND_TRY(run_conv(p, blob, w, C_M0, corr, nullptr, nullptr, B, H, W, s));
+        NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
+    }
     return NND_OK;
 }
 
@@ -348,7 +376,8 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
         one(C_Q2, 20);
         k = 22;
     }
-    two(C_FM1, k, k + 4, hid, 2 * hid);  // flow_head.conv1 | mask.0
+    one(C_FH1, k);
+    one(C_M0, k + 4);
     one(C_FC2, k + 2);
     one(C_M2, k + 6);
     return NND_OK;
@@ -408,12 +437,58 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
     hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H, W);
     NND_LAUNCH_CHECK();
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
-    for (int it = 0; it < iters; ++it) {
-        NND_TRY(corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, s));
-        NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
-        hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W);
-        NND_LAUNCH_CHECK();
-        NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s));
+    static const bool single = getenv("NND_SINGLE_STREAM") != nullptr;
+    Streams* st = single ? nullptr : side_streams();
+    if (!st) {  // plain in-order version (also the debugging reference for the DAG below)
+        for (int it = 0; it < iters; ++it) {
+            NND_TRY(corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, s));
+            NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
+            hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W);
+            NND_LAUNCH_CHECK();
+            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s));
+        }
+    } else {
+        // Per-iteration DAG over three streams (M = caller's stream carries the recurrence):
+        //   M: lookup, convc1, convc2, [f2] conv, zr1, q1*, zr2, q2 ->(q2) flow_head.conv1, conv2, advance**  ->(adv)
+        //   A: (start) convf1, convf2 ->(f2)                         flow branch of the motion encoder
+        //   B: (q2) mask.0 ->(m0) mask.2, (adv) convex upsample ->(up)   output-only work, overlaps iteration i+1
+        //   * q1 of the next iteration overwrites h: waits m0.   ** advance overwrites flow: waits up.
+        NND_HIP_CHECK(hipEventRecord(st->start, s));
+        for (int it = 0; it < iters; ++it) {
+            NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->start, 0));
+            NND_TRY(run_convf1(p, packed, w.flow, (int64_t)n, w.f1, B, H, W, st->a));
+            NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
+            NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
+            NND_TRY(corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, s));
+            NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
+            NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
+            NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(run_conv(p, packed, w, C_ZR1, c, nullptr, nullptr, B, H, W, s));
+            if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->m0, 0));
+            NND_TRY(run_conv(p, packed, w, C_Q1, c, nullptr, nullptr, B, H, W, s));
+            if (p.sep) {
+                NND_TRY(run_conv(p, packed, w, C_ZR2, c, nullptr, nullptr, B, H, W, s));
+                NND_TRY(run_conv(p, packed, w, C_Q2, c, nullptr, nullptr, B, H, W, s));
+            }
+            NND_HIP_CHECK(hipEventRecord(st->q2, s));
+            NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->q2, 0));
+            NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, st->b));
+            NND_HIP_CHECK(hipEventRecord(st->m0, st->b));
+            NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, st->b));
+            NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(run_conv(p, packed, w, C_FC2, c, nullptr, w.delta, B, H, W, s));
+            if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
+            hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W);
+            NND_LAUNCH_CHECK();
+            NND_HIP_CHECK(hipEventRecord(st->adv, s));
+            NND_HIP_CHECK(hipEventRecord(st->start, s));
+            NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
+            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, st->b));
+            NND_HIP_CHECK(hipEventRecord(st->up, st->b));
+        }
+        NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));   // join B
+        NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));   // join A (already consumed, keeps the contract simple)
     }
     if (low_out) NND_TRY(copy_slice(low_out, n, w.flow, n, n, B, s));
     if (net_out) NND_TRY(copy_slice(net_out, hid * n, w.hx, hxC * n, hid * n, B, s));
