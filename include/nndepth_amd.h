@@ -116,6 +116,13 @@ int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin,
 int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
                        int Cout, int KH, int KW, int relu, void* stream);
 
+/* Fused tail of the mask head + convex upsample (the (B, 9*rate^2, H, W) mask is never written):
+ *   out = convex_upsample(flow, 0.25 * conv1x1(x; W, b))      x (B,Cin,H,W), flow (B,1,H,W), out (B,1,rate*H,rate*W)
+ * Replaces update_block.py:97-101,111 (mask.2, x0.25) + raft_stereo/model.py:93-105.  `packed_dev` is the blob of
+ * nnd_conv2d_pack for the (9*rate^2, Cin, 1, 1) weight.  Built for rate 4 / 8 and Cin 128 / 256.            */
+int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const float* flow, float* out,
+                              int B, int Cin, int H, int W, int rate, void* stream);
+
 /* ------------------------------------------------------------------ fused refinement loop
  * Replaces the `for _ in range(self.iters)` loop of RAFTStereo.forward
  *   nndepth/models/raft_stereo/model.py:126-137 (+ initialize_coords :87-91)

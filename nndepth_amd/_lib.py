@@ -38,6 +38,7 @@ SIGNATURES = {
     "nnd_conv2d_packed_floats": (C.c_int64, [_I, _I, _I, _I]),
     "nnd_conv2d_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "nnd_conv2d_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_mask_upsample_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_raft_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),

@@ -46,8 +46,10 @@ enum ConvEpilogue {
     EPI_RELU = 1,    // out0 = max(v, 0)
     EPI_GRU_ZR = 2,  // co <  hidden: out0[co] = sigmoid(v)                (z)
                      // co >= hidden: out1[co-hidden] = sigmoid(v) * aux0  (r*h)
-    EPI_GRU_Q = 3,   // q = tanh(v); out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z)
-    EPI_SCALE = 4    // out0 = scale * v
+    EPI_GRU_Q = 3,   // q = tanh(v); out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z); out1 (optional) = copy
+    EPI_SCALE = 4,   // out0 = scale * v
+    EPI_ADVANCE = 5  // Cout = 1: delta = v -> out0; coords (aux0, in/out) += delta; flow = coords - x -> out1 and aux1
+                     // (nndepth/models/raft_stereo/model.py:134-135 fused into flow_head.conv2)
 };
 
 // One convolution layer inside a packed parameter blob.
@@ -92,5 +94,10 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
                          int radius, hipStream_t stream);
 int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
                            hipStream_t stream);
+
+// mask_upsample.hip: fused mask.2 (1x1, x0.25) + softmax + convex upsample (mask never written)
+bool mask_upsample_supported(int rate, int cin, int flow_channels);
+int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
+                         int B, int H, int W, int rate, hipStream_t stream);
 
 }  // namespace nnd

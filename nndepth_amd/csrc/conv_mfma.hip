@@ -361,9 +361,20 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
                 const float sg = sigmoidf_(v);
                 if (co < a.hidden) a.out0[b * a.obs0 + co * HW + pix] = sg;
                 else a.out1[b * a.obs1 + (co - a.hidden) * HW + pix] = sg * h_r[reg];
-            } else {  // EPI_GRU_Q
+            } else if (epi == EPI_GRU_Q) {
                 const float q = tanhf_(v);
-                a.out0[b * a.obs0 + co * HW + pix] = (1.0f - z_r[reg]) * h_r[reg] + z_r[reg] * q;
+                const float hn = (1.0f - z_r[reg]) * h_r[reg] + z_r[reg] * q;
+                a.out0[b * a.obs0 + co * HW + pix] = hn;
+                if (a.out1) a.out1[b * a.obs1 + co * HW + pix] = hn;
+            } else {  // EPI_ADVANCE (Cout == 1: only co == 0 reaches here)
+                float* coords = const_cast<float*>(a.aux0);
+                float* hx_flow = const_cast<float*>(a.aux1);
+                const float cnew = coords[b * a.abs0 + pix] + v;
+                const float f = cnew - (float)x;
+                a.out0[b * a.obs0 + pix] = v;
+                coords[b * a.abs0 + pix] = cnew;
+                a.out1[b * a.obs1 + pix] = f;
+                hx_flow[b * a.abs1 + pix] = f;
             }
         }
     }

@@ -1,0 +1,225 @@
+// Fused mask head tail + convex upsample:   up = convex_upsample(flow, 0.25 * conv1x1(x))
+//   x = relu(mask.0(h)) (B, CIN, H, W)  ->  mask (9*R*R channels, NEVER written to HBM)  ->  softmax over the 9
+//   neighbours  ->  up (B, 1, R*H, R*W).
+// Replaces nndepth/blocks/update_block.py:97-101,111 (mask.2 and the 0.25 scale) followed by
+// nndepth/models/raft_stereo/model.py:93-105 (convex_upsample); saves writing + re-reading the 18.8 MB mask per
+// iteration ("K8 fused with the 1x1 mask conv's epilogue").
+//
+// One workgroup = one 4x8 pixel tile x ALL 9*R*R mask channels:
+//   * the whole x tile (CIN x 32 px) is staged in LDS once (no per-chunk barriers in the K loop);
+//   * G x 2 waves: wave (g, kj) accumulates CBW output-channel blocks over half of K on the fp32 MFMA with the
+//     same packed-weight stream as conv_mfma (A: global -> VGPR in fragment order, B: LDS);
+//   * the two K-halves are summed into an LDS mask tile [9*R*R][33]; then every thread produces output pixels:
+//     9 logits from LDS -> softmax -> weighted sum of the 3x3 flow neighbourhood -> R*8 contiguous floats per
+//     (tile row, sub-row) so the HBM stores are whole 256-B runs.
+#include "common.h"
+
+namespace nnd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MaskUpArgs {
+    const float* x;
+    long xbs;
+    const float* wpk;
+    const float* bias;
+    const float* flow;  // (B,1,H,W)
+    float* out;         // (B,1,R*H,R*W)
+    int H, W, tiles_x;
+};
+
+template <int RATE, int CIN>
+struct MaskUpCfg {
+    static constexpr int COUT = 9 * RATE * RATE;
+    static constexpr int NCB = (COUT + 31) / 32;
+    static constexpr int CBW = NCB >= 12 ? 3 : 1;        // channel blocks per wave
+    static constexpr int G = (NCB + CBW - 1) / CBW;      // wave groups along Cout
+    static constexpr int NWAVES = 2 * G;                 // x 2 K-halves
+    static constexpr int NT = 64 * NWAVES;
+    static constexpr int NST = CIN / 32;                 // 32-channel steps over K
+    static constexpr int MT_STRIDE = 33;
+    static constexpr int LDS_FLOATS = (CIN * 32 > COUT * MT_STRIDE ? CIN * 32 : COUT * MT_STRIDE) + 64;
+};
+
+template <int RATE, int CIN>
+__global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kernel(MaskUpArgs a) {
+    using Cfg = MaskUpCfg<RATE, CIN>;
+    constexpr int COUT = Cfg::COUT, NCB = Cfg::NCB, CBW = Cfg::CBW, G = Cfg::G, NT = Cfg::NT, NST = Cfg::NST;
+    constexpr int CI_T = 128;                 // packing of a 1x1 conv with Cin >= 128 (conv_ci_t)
+    constexpr int NCHUNK = CIN / CI_T;
+    constexpr int MTS = Cfg::MT_STRIDE;
+    static_assert(CIN % 128 == 0 && NST % 2 == 0, "CIN must be a multiple of 128");
+    extern __shared__ float lds[];
+    float* xs = lds;                          // [CIN][32]   (K loop)
+    float* mt = lds;                          // [COUT][33]  (after the K loop; aliases xs)
+    float* fp = lds + Cfg::LDS_FLOATS - 64;   // [6][10] flow patch, zero outside the image
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave % G, kj = wave / G;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int tx0 = (blockIdx.x % a.tiles_x) * 8, ty0 = (blockIdx.x / a.tiles_x) * 4;
+    const int b = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const long HW = (long)H * W;
+
+    // ---- stage the x tile (all CIN channels) and the flow patch
+    {
+        const float* src = a.x + b * a.xbs;
+        constexpr int NLD = (CIN * 32 + NT - 1) / NT;
+        float v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * NT;
+            const int ci = e >> 5, px = e & 31;
+            const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
+            const bool ok = e < CIN * 32 && y < H && x < W;
+            v[i] = src[ok ? (unsigned)(ci * (int)HW + y * W + x) : 0u];
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * NT;
+            const int px = e & 31;
+            const bool ok = (ty0 + (px >> 3)) < H && (tx0 + (px & 7)) < W;
+            if (e < CIN * 32) xs[e] = ok ? v[i] : 0.f;
+        }
+        if (tid < 60) {
+            const int pr = tid / 10, pc = tid % 10;
+            const int y = ty0 + pr - 1, x = tx0 + pc - 1;
+            fp[tid] = (y >= 0 && y < H && x >= 0 && x < W) ? a.flow[b * HW + (long)y * W + x] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop: units u = (step, cbi); A of unit u+1 is prefetched during unit u, B of step s+1 during step s
+    f32x16 acc[CBW];
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    constexpr int SPW = NST / 2;  // steps per wave
+    const int s0 = kj * SPW;
+    const float4* wq = reinterpret_cast<const float4*>(a.wpk);
+    auto a_base = [&](int cbi) {
+        int cb = g * CBW + cbi;
+        cb = cb < NCB ? cb : NCB - 1;  // padded group member: re-reads a valid block, result discarded
+        return wq + (size_t)cb * (NCHUNK * 16 * 64);
+    };
+    float4 ab[2][4];
+    float bq[2][16];
+    auto load_a = [&](float4* dst, int u) {  // u = local unit index
+        const int s = s0 + u / CBW, cbi = u % CBW;
+        const float4* ws = a_base(cbi) + s * (4 * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = ws[(unsigned)(q * 64 + lane)];
+    };
+    auto load_b = [&](float* dst, int sl) {
+        const float* xb = xs + ((s0 + sl) * 32 + h2) * 32 + l31;
+#pragma unroll
+        for (int pair = 0; pair < 16; ++pair) dst[pair] = xb[pair * 64];
+    };
+    load_a(ab[0], 0);
+    load_b(bq[0], 0);
+#pragma unroll
+    for (int u = 0; u < SPW * CBW; ++u) {
+        const int sl = u / CBW, cbi = u % CBW;
+        if (u + 1 < SPW * CBW) load_a(ab[(u + 1) & 1], u + 1);
+        if (cbi == 0 && sl + 1 < SPW) load_b(bq[(sl + 1) & 1], sl + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pair = 0; pair < 16; ++pair) {
+            const float4 av = ab[u & 1][pair / 4];
+            const float as = (pair % 4 == 0) ? av.x : (pair % 4 == 1) ? av.y : (pair % 4 == 2) ? av.z : av.w;
+            acc[cbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bq[sl & 1][pair], acc[cbi], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // everyone is done reading xs: the mask tile may overwrite it
+
+    // ---- sum the two K-halves into the LDS mask tile [COUT][33]
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (kj == pass) {
+#pragma unroll
+            for (int cbi = 0; cbi < CBW; ++cbi) {
+                const int cb = g * CBW + cbi;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                    if (cb < NCB && co < COUT) {
+                        float* p = mt + co * MTS + l31;
+                        *p = pass == 0 ? acc[cbi][reg] : *p + acc[cbi][reg];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- softmax over the 9 neighbours + convex combination; item = (tile row rr, sub-row i) x (col c, sub-col j)
+    constexpr int ROWLEN = 8 * RATE;          // contiguous output floats per item row
+    constexpr int NITEM = 4 * RATE * ROWLEN;  // outputs per tile
+    const long OW = (long)W * RATE;
+    for (int e = tid; e < NITEM; e += NT) {
+        const int seg = e / ROWLEN, within = e % ROWLEN;
+        const int rr = seg / RATE, i = seg % RATE;
+        const int c = within / RATE, j = within % RATE;
+        const int px = rr * 8 + c;
+        const int y = ty0 + rr, x = tx0 + c;
+        float m[9];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int co = k * RATE * RATE + i * RATE + j;
+            m[k] = 0.25f * (mt[co * MTS + px] + a.bias[co]);
+            mx = fmaxf(mx, m[k]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            m[k] = expf(m[k] - mx);
+            sum += m[k];
+        }
+        float o = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o += (m[k] / sum) * ((float)RATE * fp[(rr + k / 3) * 10 + c + k % 3]);
+        if (y < H && x < W) a.out[(long)b * HW * RATE * RATE + ((long)y * RATE + i) * OW + (long)x * RATE + j] = o;
+    }
+}
+
+template <int RATE, int CIN>
+static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
+    using Cfg = MaskUpCfg<RATE, CIN>;
+    auto kern = mask_upsample_kernel<RATE, CIN>;
+    const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    dim3 grid(a.tiles_x * cdiv(a.H, 4), 1, B), block(Cfg::NT);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+bool mask_upsample_supported(int rate, int cin, int flow_channels) {
+    return flow_channels == 1 && ((rate == 8 && (cin == 256 || cin == 128)) || (rate == 4 && (cin == 256 || cin == 128)));
+}
+
+int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
+                         int B, int H, int W, int rate, hipStream_t stream) {
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == 128 && L.Cout == 9 * rate * rate, "mask_upsample: layer shape");
+    NND_REQUIRE(mask_upsample_supported(rate, L.Cin, 1), "mask_upsample: rate %d / Cin %d not built", rate, L.Cin);
+    MaskUpArgs a;
+    a.x = x; a.xbs = xbs; a.wpk = blob + L.w_off; a.bias = blob + L.b_off; a.flow = flow; a.out = out;
+    a.H = H; a.W = W; a.tiles_x = cdiv(W, 8);
+    if (rate == 8 && L.Cin == 256) return launch_mu<8, 256>(a, B, stream);
+    if (rate == 8 && L.Cin == 128) return launch_mu<8, 128>(a, B, stream);
+    if (rate == 4 && L.Cin == 256) return launch_mu<4, 256>(a, B, stream);
+    return launch_mu<4, 128>(a, B, stream);
+}
+
+}  // namespace nnd

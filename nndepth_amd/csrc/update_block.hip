@@ -85,7 +85,7 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
 
 // ------------------------------------------------------------------------------- workspace
 struct Bufs {
-    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow;
+    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow, *hcopy;
     int64_t total;
 };
 
@@ -110,6 +110,7 @@ static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
     b->delta = take(fc);
     b->coords = take(1);
     b->flow = take(fc);
+    b->hcopy = take(2 * hid);  // double-buffered copy of h for the mask branch (side stream)
     b->total = off;
 }
 
@@ -189,7 +190,13 @@ __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict
 static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
 
 // IO of conv `id` given the workspace; `corr` / `flow_src` are the external inputs.
-static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*H*W*/, float* mask_dst, float* delta_dst) {
+struct IoOpt {
+    int parity = -1;       // >= 0: last GRU q also writes hcopy[parity]; mask.0 reads it
+    bool advance = false;  // flow_head.conv2 runs the fused coords/flow update
+};
+
+static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*H*W*/, float* mask_dst, float* delta_dst,
+                      IoOpt opt = IoOpt()) {
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels;
     const int hxC = 2 * hid + ctx;
     ConvIO io{};
@@ -213,10 +220,22 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.out0 = act(w.hx, hxC * n, hid);
             io.aux0 = act(w.hx, hxC * n, hid);
             io.aux1 = act(w.z, hid * n, hid);
+            if (opt.parity >= 0 && id == (p.sep ? C_Q2 : C_Q1)) io.out1 = act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid);
             break;
         case C_FH1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, hid); break;
-        case C_M0: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid); break;
-        case C_FC2: io.src0 = act(w.fm, 3 * hid * n, hid); io.out0 = act(delta_dst, fc * n, fc); break;
+        case C_M0:
+            io.src0 = opt.parity >= 0 ? act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid) : act(w.hx, hxC * n, hid);
+            io.out0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
+            break;
+        case C_FC2:
+            io.src0 = act(w.fm, 3 * hid * n, hid);
+            io.out0 = act(delta_dst, fc * n, fc);
+            if (opt.advance) {
+                io.out1 = act(w.flow, n, 1);
+                io.aux0 = act(w.coords, n, 1);
+                io.aux1 = act(w.hx + (hxC - 1) * n, hxC * n, 1);
+            }
+            break;
         case C_M2:
             io.src0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
             io.out0 = act(mask_dst, p.d.mask_channels * n, p.d.mask_channels);
@@ -226,7 +245,8 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
     return io;
 }
 
-static int conv_epi(int id) {
+static int conv_epi(int id, IoOpt opt = IoOpt()) {
+    if (id == C_FC2 && opt.advance) return EPI_ADVANCE;
     switch (id) {
         case C_ZR1: case C_ZR2: return EPI_GRU_ZR;
         case C_Q1: case C_Q2: return EPI_GRU_Q;
@@ -249,9 +269,9 @@ static int debug_sync(const char* what, hipStream_t s) {
 }
 
 static int run_conv(const Plan& p, const float* blob, const Bufs& w, int id, Act corr, float* mask_dst, float* delta_dst,
-                    int B, int H, int W, hipStream_t s) {
-    ConvIO io = conv_io(p, w, id, corr, (int64_t)H * W, mask_dst, delta_dst);
-    int rc = launch_conv(p.L[id], blob, io, conv_epi(id), B, H, W, s);
+                    int B, int H, int W, hipStream_t s, IoOpt opt = IoOpt()) {
+    ConvIO io = conv_io(p, w, id, corr, (int64_t)H * W, mask_dst, delta_dst, opt);
+    int rc = launch_conv(p.L[id], blob, io, conv_epi(id, opt), B, H, W, s);
     if (rc != NND_OK) return rc;
     return debug_sync(kConvNames[id], s);
 }
@@ -273,7 +293,7 @@ static int run_convf1(const Plan& p, const float* blob, const float* flow, int64
 // state of the library); all cross-stream edges are explicit events, the caller's stream is joined at the end.
 struct Streams {
     hipStream_t a = nullptr, b = nullptr;  // a: flow branch, b: mask/upsample branch
-    hipEvent_t start = nullptr, f2 = nullptr, q2 = nullptr, m0 = nullptr, adv = nullptr, up = nullptr;
+    hipEvent_t f2 = nullptr, q2 = nullptr, adv = nullptr, up = nullptr;
     bool ok = false;
 };
 static Streams* side_streams() {
@@ -284,7 +304,7 @@ static Streams* side_streams() {
     if (!s.ok) {
         if (hipStreamCreateWithFlags(&s.a, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&s.b, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (hipEvent_t* e : {&s.start, &s.f2, &s.q2, &s.m0, &s.adv, &s.up})
+        for (hipEvent_t* e : {&s.f2, &s.q2, &s.adv, &s.up})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
         s.ok = true;
     }
@@ -296,7 +316,10 @@ static Streams* side_streams() {
 static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr, const float* flow, float* mask_dst,
                       float* delta_dst, int B, int H, int W, hipStream_t s) {
     int rc;
-#define NND_TRY(x) if ((rc = (x)) != NND_OK) return rc
+#define NND_TRY(x)                    \
+    do {                              \
+        if ((rc = (x)) != NND_OK) return rc; \
+    } while (0)
     NND_TRY(run_conv(p, blob, w, C_C1, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_C2, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_convf1(p, blob, flow, (int64_t)p.d.flow_channels * H * W, w.f1, B, H, W, s));
@@ -449,13 +472,19 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
         }
     } else {
         // Per-iteration DAG over three streams (M = caller's stream carries the recurrence):
-        //   M: lookup, convc1, convc2, [f2] conv, zr1, q1*, zr2, q2 ->(q2) flow_head.conv1, conv2, advance**  ->(adv)
-        //   A: (start) convf1, convf2 ->(f2)                         flow branch of the motion encoder
-        //   B: (q2) mask.0 ->(m0) mask.2, (adv) convex upsample ->(up)   output-only work, overlaps iteration i+1
-        //   * q1 of the next iteration overwrites h: waits m0.   ** advance overwrites flow: waits up.
-        NND_HIP_CHECK(hipEventRecord(st->start, s));
+        //   M: lookup, convc1, convc2, [f2] conv, zr1, q1, zr2, q2 (+h copy) ->(q2) flow_head.conv1, [up] conv2+advance ->(adv)
+        //   A: (adv) convf1, convf2 ->(f2)                              flow branch of the motion encoder
+        //   B: (q2) mask.0, mask.2, (adv) convex upsample ->(up)         output-only work, overlaps iteration i+1
+        // Hazards: mask.0 reads the h copy of parity it&1 (q2 of it+2 rewrites it only after advance(it+1), which
+        // waited for up(it), and B runs mask.0(it) before up(it)); advance(it+1) rewrites flow only after up(it).
+        static const bool no_fuse = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;
+        const bool fused_up = !no_fuse && mask_upsample_supported(rate, 2 * hid, 1);
+        NND_HIP_CHECK(hipEventRecord(st->adv, s));
         for (int it = 0; it < iters; ++it) {
-            NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->start, 0));
+            IoOpt opt;
+            opt.parity = it & 1;
+            opt.advance = true;
+            NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
             NND_TRY(run_convf1(p, packed, w.flow, (int64_t)n, w.f1, B, H, W, st->a));
             NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
             NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
@@ -465,26 +494,25 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
             NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
             NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_ZR1, c, nullptr, nullptr, B, H, W, s));
-            if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->m0, 0));
-            NND_TRY(run_conv(p, packed, w, C_Q1, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(run_conv(p, packed, w, C_Q1, c, nullptr, nullptr, B, H, W, s, opt));
             if (p.sep) {
                 NND_TRY(run_conv(p, packed, w, C_ZR2, c, nullptr, nullptr, B, H, W, s));
-                NND_TRY(run_conv(p, packed, w, C_Q2, c, nullptr, nullptr, B, H, W, s));
+                NND_TRY(run_conv(p, packed, w, C_Q2, c, nullptr, nullptr, B, H, W, s, opt));
             }
             NND_HIP_CHECK(hipEventRecord(st->q2, s));
             NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->q2, 0));
-            NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, st->b));
-            NND_HIP_CHECK(hipEventRecord(st->m0, st->b));
-            NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, st->b));
+            NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, st->b, opt));
+            if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, st->b));
             NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
-            NND_TRY(run_conv(p, packed, w, C_FC2, c, nullptr, w.delta, B, H, W, s));
             if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
-            hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W);
-            NND_LAUNCH_CHECK();
+            NND_TRY(run_conv(p, packed, w, C_FC2, c, nullptr, w.delta, B, H, W, s, opt));
             NND_HIP_CHECK(hipEventRecord(st->adv, s));
-            NND_HIP_CHECK(hipEventRecord(st->start, s));
             NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
-            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, st->b));
+            if (fused_up)  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
+                NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow,
+                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, st->b));
+            else
+                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, st->b));
             NND_HIP_CHECK(hipEventRecord(st->up, st->b));
         }
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));   // join B
@@ -535,6 +563,16 @@ int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B,
     io.src0 = act(const_cast<float*>(x), Cin * n, Cin);
     io.out0 = act(y, Cout * n, Cout);
     return launch_conv(L, packed_dev, io, relu ? EPI_RELU : EPI_LINEAR, B, H, W, (hipStream_t)stream);
+}
+
+int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const float* flow, float* out, int B, int Cin, int H,
+                              int W, int rate, void* stream) {
+    ConvLayer L;
+    int rc = conv2d_layer(9 * rate * rate, Cin, 1, 1, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev && x && flow && out && B > 0 && H > 0 && W > 0, "mask_upsample_forward: bad argument");
+    NND_REQUIRE(mask_upsample_supported(rate, Cin, 1), "mask_upsample_forward: rate %d / Cin %d not built", rate, Cin);
+    return mask_upsample_launch(L, packed_dev, x, (int64_t)Cin * H * W, flow, out, B, H, W, rate, (hipStream_t)stream);
 }
 
 int nnd_num_convs(const nnd_update_block_desc* desc) {

@@ -111,6 +111,18 @@ class Conv2d:
         return y
 
 
+def mask_upsample(conv: "Conv2d", x: torch.Tensor, flow: torch.Tensor, rate: int) -> torch.Tensor:
+    """convex_upsample(flow, 0.25 * conv1x1(x)) in one kernel; `conv` = Conv2d packed from mask.2's (9r^2,Cin,1,1)."""
+    d = _dev(x, flow, conv.packed)
+    x, flow = x.contiguous(), flow.contiguous()
+    B, Cin, H, W = x.shape
+    out = torch.empty((B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_mask_upsample_forward(_p(conv.packed), _p(x), _p(flow), _p(out), B, Cin, H, W, rate, _stream(d)),
+              "mask_upsample_forward")
+    return out
+
+
 # --------------------------------------------------------------------------- update block
 # order of the reference module's state_dict (nndepth/blocks/update_block.py:39-55,68-101)
 def update_block_keys(gru: str = "sep_conv") -> List[str]:

@@ -253,3 +253,14 @@ def test_batch_consistency(raft_sd):
     oa = m(a1.to(DEV), a2.to(DEV))[-1]["up_disp"]
     ob = m(b1.to(DEV), b2.to(DEV))[-1]["up_disp"]
     assert (both[0] - oa[0]).abs().max() <= 2e-5 and (both[1] - ob[0]).abs().max() <= 2e-5
+
+
+def test_fused_mask_upsample_matches_unfused(raft_sd, monkeypatch):
+    """The fused mask.2+softmax+upsample kernel (mask never written) == mask.2 conv followed by the
+    standalone convex_upsample kernel, on the same loop (seam-by-seam path uses the unfused kernels)."""
+    from nndepth_amd import weightgen
+    f1, f2 = weightgen.synthetic_frames(3, 1, 96, 160)
+    a = _model(raft_sd, 5, fused=True)(f1.to(DEV), f2.to(DEV))
+    b = _model(raft_sd, 5, fused=False)(f1.to(DEV), f2.to(DEV))
+    for i in range(5):
+        assert (a[i]["up_disp"] - b[i]["up_disp"]).abs().max() <= 2e-5, i
