@@ -14,7 +14,8 @@
  *   - all work is enqueued on the caller-supplied hipStream_t (`stream`, may be NULL);
  *   - return value: 0 on success, negative nnd_status on failure (never throws);
  *     nnd_last_error() gives a thread-local message for the last failure;
- *   - no global mutable state besides a read-only device-property cache.
+ *   - no global mutable state except two lazily created, mutex-guarded side streams (+4 events) per device
+ *     that nnd_raft_stereo_refine forks from / joins back into the caller's stream with events.
  */
 #ifndef NNDEPTH_AMD_H
 #define NNDEPTH_AMD_H

@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace nnd {
@@ -298,12 +299,19 @@ struct Streams {
 };
 static Streams* side_streams() {
     static Streams st[16];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     Streams& s = st[dev];
     if (!s.ok) {
-        if (hipStreamCreateWithFlags(&s.a, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithFlags(&s.b, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        // lowest priority: the side branches only fill the bubbles of the recurrence on the caller's stream
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        static const bool flat = getenv("NND_FLAT_PRIORITY") != nullptr;
+        if (flat) least = 0;
+        if (hipStreamCreateWithPriority(&s.a, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithPriority(&s.b, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
         for (hipEvent_t* e : {&s.f2, &s.q2, &s.adv, &s.up})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
         s.ok = true;
