@@ -264,3 +264,35 @@ def test_fused_mask_upsample_matches_unfused(raft_sd, monkeypatch):
     b = _model(raft_sd, 5, fused=False)(f1.to(DEV), f2.to(DEV))
     for i in range(5):
         assert (a[i]["up_disp"] - b[i]["up_disp"]).abs().max() <= 2e-5, i
+
+
+def test_forward_kitti_shape_batch2_vs_oracle(raft_sd, R):
+    """configs[3] shape: KITTI 375x1242 padded to 384x1248 (Padder(32)) -> 48x156 at 1/8 (156 is not a multiple of
+    the 8-pixel tile width: ragged last tile), batch 2, vs the oracle on the same seeded input."""
+    from nndepth_amd import weightgen
+    f1, f2 = weightgen.synthetic_frames(7, 2, 384, 1248)
+    out = _model(raft_sd, 3)(f1.to(DEV), f2.to(DEV))
+    with torch.no_grad():
+        ref = R.raft_stereo_forward(raft_sd, f1, f2, 3)
+    assert tuple(out[-1]["up_disp"].shape) == (2, 1, 384, 1248)
+    for i in range(3):
+        err = (out[i]["up_disp"].cpu() - ref[i]).abs().max().item()
+        assert err <= 1e-4, f"iter {i}: {err}"
+
+
+def test_conv2d_generic_shapes():
+    """The generic fp32-MFMA conv behind the update block, on ragged shapes (Cout not a multiple of 32, Cin not a
+    multiple of the 32-channel chunk, image smaller than a tile, batch > 1) against torch's CPU conv."""
+    from nndepth_amd import ops
+    torch.manual_seed(5)
+    for (Cout, Cin, KH, KW, B, H, W) in [(127, 256, 3, 3, 1, 12, 20), (5, 36, 1, 1, 2, 3, 5), (192, 320, 1, 5, 1, 9, 33),
+                                         (64, 40, 5, 1, 2, 17, 9), (576, 256, 1, 1, 1, 8, 12), (33, 7, 3, 3, 3, 4, 4)]:
+        w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
+        b = torch.randn(Cout)
+        x = torch.randn(B, Cin, H, W)
+        conv = ops.Conv2d(w, b)
+        ref = torch.nn.functional.conv2d(x, w, b, padding=(KH // 2, KW // 2))
+        for relu in (False, True):
+            y = conv(x.to(DEV), relu=relu).cpu()
+            exp = torch.relu(ref) if relu else ref
+            assert (y - exp).abs().max() <= 2e-5, (Cout, Cin, KH, KW, B, H, W, relu)
