@@ -63,6 +63,22 @@ int nnd_corr1d_build(const float* fmap1, const float* fmap2, float* pyramid,
 int nnd_corr1d_lookup(const float* pyramid, const float* coords, float* out,
                       int B, int H, int W, int num_levels, int radius, void* stream);
 
+/* ------------------------------------------------------------ IGEV geometry-encoding volume
+ * Replaces GeometryAwareCostVolume.build_cost_volume + the avg-pool pyramids + forward (combined lookup)
+ *   nndepth/models/igev_stereo/cost_volume.py:81-98, :40-52, :54-79
+ * Group g correlates channels [g*group_channels, (g+1)*group_channels) of the Ctot-channel maps (the reference
+ * uses only the first num_groups chunks of num_groups channels) and divides by sqrt(group_channels).
+ * Pyramids use the layout of nnd_corr1d_pyramid_layout(B*num_groups, H, W, num_levels): rows ordered (b,g,h,w1),
+ * so level 0 viewed as (B,G,H,W1,W2) is the tensor the 3-D regulariser (PyTorch) consumes.
+ * nnd_pyramid_from_level0 fills levels 1..num_levels of a pyramid whose level 0 was written by the caller (the
+ * regularised volume).  nnd_igev_lookup: coords (B,1,H,W) -> out (B, num_levels*2*G*(2r+1), H, W), channel
+ * = i*2*G*T + v*G*T + g*T + k with v = 0 feature / 1 geometry volume.                                   */
+int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
+                         int num_groups, int group_channels, int num_levels, void* stream);
+int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels, void* stream);
+int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out,
+                    int B, int G, int H, int W, int num_levels, int radius, void* stream);
+
 /* ----------------------------------------------------------------------- convex upsample
  * Replaces RAFTStereo.convex_upsample  nndepth/models/raft_stereo/model.py:93-105
  * (IGEV copy igev_stereo/model.py:103-115; 2-channel CRE copy cre_stereo/model.py:110-122)

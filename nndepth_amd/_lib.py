@@ -29,6 +29,9 @@ SIGNATURES = {
     "nnd_corr1d_pyramid_layout": (_I, [_I, _I, _I, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "nnd_corr1d_build": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_corr1d_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_group_corr_build": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_pyramid_from_level0": (_I, [_P, _I, _I, _I, _I, _P]),
+    "nnd_igev_lookup": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_convex_upsample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_update_block_num_tensors": (_I, [C.POINTER(UpdateBlockDesc)]),
     "nnd_update_block_packed_floats": (C.c_int64, [C.POINTER(UpdateBlockDesc)]),

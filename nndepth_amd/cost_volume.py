@@ -34,3 +34,42 @@ class CorrBlock1D:
         B, _, H, W = fmap1.shape
         pyr = ops.corr1d_build(fmap1.float(), fmap2.float(), 1)
         return pyr[:B * H * W * W].view(B, H, W, W)
+
+
+class GeometryAwareCostVolume:
+    """Drop-in for IGEV's `GeometryAwareCostVolume` (nndepth/models/igev_stereo/cost_volume.py:9-98): same
+    constructor arguments, `feat_corr_cv` / `geo_aware_cv` pyramid lists (num_levels+1 entries shaped
+    (B*G*H*W, 1, W_l), `forward()` reads `geo_aware_cv[0]`, igev_stereo/model.py:144) and `corr(coords)`.
+    The group-wise correlation, both avg-pool pyramids and the combined lookup are HIP kernels; the 3-D
+    regulariser passed in (`regularizer_3d`, Conv3d hourglass) runs on PyTorch-ROCm."""
+
+    def __init__(self, fmap1, fmap2, features, regularizer_3d, num_levels: int = 4, radius: int = 4, num_groups: int = 8):
+        self.num_groups, self.num_levels, self.radius = num_groups, num_levels, radius
+        B, C, H, W = fmap1.shape
+        assert C % num_groups == 0, "Number of channels of fmap1 and fmap2 must be the factor of num_groups"
+        self.shape = (B, H, W)
+        # torch.split(fmap, num_groups) yields chunks of num_groups channels; only the first num_groups are used (Q4)
+        self._feat = ops.group_corr_build(fmap1.float(), fmap2.float(), num_groups, num_groups, num_levels)
+        feat0 = self._feat[:B * num_groups * H * W * W].view(B, num_groups, H, W, W)
+        geo = regularizer_3d(feat0.clone().permute(0, 1, 4, 2, 3), features)          # (B, G, W2, H, W1)
+        geo0 = geo.permute(0, 1, 3, 4, 2).contiguous().float()                          # (B, G, H, W1, W2)
+        self._geo = ops.pyramid_from_level0(geo0.view(-1, W), B * num_groups, H, W, num_levels)
+
+    def _views(self, pyr):
+        B, H, W = self.shape
+        n = B * self.num_groups * H * W
+        offs, widths, _ = ops.pyramid_layout(B * self.num_groups, H, W, self.num_levels)
+        return [pyr[o:o + n * w].view(n, 1, w) for o, w in zip(offs, widths)]
+
+    @property
+    def feat_corr_cv(self):
+        return self._views(self._feat)
+
+    @property
+    def geo_aware_cv(self):
+        return self._views(self._geo)
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        return ops.igev_lookup(self._feat, self._geo, coords.float(), self.num_groups, self.num_levels, self.radius)
+
+    forward = __call__

@@ -42,15 +42,18 @@ static void make_layout(int B, int H, int W, int stored_levels, PyrLayout* L, in
 }
 
 // grid: (ceil(W/32) w1-blocks, H, B); block: 256 threads = 4 waves, wave t takes w2 tiles t, t+4, ...
+// Group-wise variant (IGEV, igev_stereo/cost_volume.py:81-98): blockIdx.z = b*G + g, the dot product runs over
+// the C channels [g*C, (g+1)*C) of a Ctot-channel map; pyramid rows are ordered (b, g, h, w1).  RAFT: G = 1.
 __global__ void __launch_bounds__(256) corr1d_build_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                            float* __restrict__ pyr, PyrLayout L, int C, int H, int W,
-                                                           float rscale_div) {
+                                                           float rscale_div, int Ctot, int G) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h2 = lane >> 5;
     const int w1_0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
     const long HW = (long)H * W;
-    const float* a_base = f1 + ((long)b * C) * HW + (long)h * W;
-    const float* b_base = f2 + ((long)b * C) * HW + (long)h * W;
+    const long chan0 = (long)(b / G) * Ctot + (long)(b % G) * C;
+    const float* a_base = f1 + chan0 * HW + (long)h * W;
+    const float* b_base = f2 + chan0 * HW + (long)h * W;
     const int w1 = w1_0 + l31;
     const bool a_ok = w1 < W;
     const int ntile = (W + 31) / 32;
@@ -109,6 +112,46 @@ __global__ void __launch_bounds__(256) corr1d_lookup_kernel(const float* __restr
     const int w2 = a.L.width[lvl];
     const float* row = pyr + a.L.off[lvl] + ((long)b * HW + pix) * w2;
     float x = (float)(k - a.radius) + coords[(long)b * HW + pix] / (float)(1 << lvl);
+    const float wm1 = (float)(w2 - 1);
+    x = x / wm1;
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    x = x * wm1;
+    const float f0 = floorf(x), f1 = ceilf(x);
+    const float v0 = row[(int)f0], v1 = row[(int)f1];
+    const float coef = f1 - x;
+    out[idx] = coef * v0 + (1.0f - coef) * v1;
+}
+
+// level l = avg_pool1d(level l-1, 2) (floor on odd widths) for a pyramid whose level 0 came from elsewhere
+// (IGEV's regularised volume, igev_stereo/cost_volume.py:46-52)
+__global__ void __launch_bounds__(256) avg_pool_level_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows,
+                                                             int w_src, int w_dst) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * w_dst) return;
+    const long row = idx / w_dst;
+    const int j = (int)(idx - row * w_dst);
+    const float* p = src + row * w_src + 2 * j;
+    dst[idx] = (p[0] + p[1]) * 0.5f;
+}
+
+// IGEV combined lookup (igev_stereo/cost_volume.py:54-79): both volumes, G groups sharing the pixel's coordinate;
+// out channel = i*(2*G*T) + v*(G*T) + g*T + k  (v = 0 feature volume, 1 geometry volume; T = 2r+1)
+__global__ void __launch_bounds__(256) igev_lookup_kernel(const float* __restrict__ feat, const float* __restrict__ geo,
+                                                          const float* __restrict__ coords, float* __restrict__ out, LookupArgs a,
+                                                          int G) {
+    const long HW = (long)a.H * a.W;
+    const int ntap = 2 * a.radius + 1;
+    const int nch = a.num_levels * 2 * G * ntap;
+    const long total = (long)a.B * nch * HW;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long pix = idx % HW;
+    const int ch = (int)((idx / HW) % nch);
+    const int b = (int)(idx / (HW * nch));
+    const int k = ch % ntap, g = (ch / ntap) % G, v = (ch / (ntap * G)) % 2, lvl = ch / (ntap * G * 2);
+    const int w2 = a.L.width[lvl];
+    const float* row = (v ? geo : feat) + a.L.off[lvl] + (((long)b * G + g) * HW + pix) * w2;
+    float x = coords[(long)b * HW + pix] / (float)(1 << lvl) + (float)(k - a.radius);
     const float wm1 = (float)(w2 - 1);
     x = x / wm1;
     x = fminf(fmaxf(x, 0.f), 1.f);
@@ -228,7 +271,53 @@ int nnd_corr1d_build(const float* fmap1, const float* fmap2, float* pyramid, int
     make_layout(B, H, W, num_levels + 1, &L, nullptr);
     dim3 grid(cdiv(W, 32), H, B), block(256);
     float div = (float)sqrt((double)C);
-    hipLaunchKernelGGL(corr1d_build_kernel, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, C, H, W, div);
+    hipLaunchKernelGGL(corr1d_build_kernel, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, C, H, W, div, C, 1);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
+                         int num_groups, int group_channels, int num_levels, void* stream) {
+    NND_REQUIRE(fmap1 && fmap2 && pyramid, "group_corr_build: null pointer");
+    NND_REQUIRE(B > 0 && H > 0 && W > 0 && num_groups > 0 && group_channels > 0 && num_groups * group_channels <= Ctot,
+                "group_corr_build: bad shape (groups %d x %d channels > %d)", num_groups, group_channels, Ctot);
+    NND_REQUIRE(num_levels >= 1 && num_levels <= 5, "group_corr_build: 1..5 pooled levels");
+    PyrLayout L;
+    make_layout(B * num_groups, H, W, num_levels + 1, &L, nullptr);
+    dim3 grid(cdiv(W, 32), H, B * num_groups), block(256);
+    float div = (float)sqrt((double)group_channels);
+    hipLaunchKernelGGL(corr1d_build_kernel, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, group_channels, H, W,
+                       div, Ctot, num_groups);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels, void* stream) {
+    NND_REQUIRE(pyramid && B > 0 && H > 0 && W > 0 && num_levels >= 1 && num_levels < MAX_LEVELS, "pyramid_from_level0: bad argument");
+    PyrLayout L;
+    make_layout(B, H, W, num_levels + 1, &L, nullptr);
+    const long rows = (long)B * H * W;
+    for (int l = 1; l <= num_levels; ++l) {
+        if (L.width[l] == 0) break;
+        long total = rows * L.width[l];
+        hipLaunchKernelGGL(avg_pool_level_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           pyramid + L.off[l - 1], pyramid + L.off[l], rows, L.width[l - 1], L.width[l]);
+        NND_LAUNCH_CHECK();
+    }
+    return NND_OK;
+}
+
+int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
+                    int W, int num_levels, int radius, void* stream) {
+    NND_REQUIRE(feat_pyramid && geo_pyramid && coords && out, "igev_lookup: null pointer");
+    NND_REQUIRE(B > 0 && G > 0 && H > 0 && W > 0 && radius >= 0 && num_levels >= 1 && num_levels < MAX_LEVELS, "igev_lookup: bad shape");
+    LookupArgs a;
+    make_layout(B * G, H, W, num_levels + 1, &a.L, nullptr);
+    a.B = B; a.H = H; a.W = W; a.num_levels = num_levels; a.radius = radius;
+    NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "igev_lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
+    long total = (long)B * num_levels * 2 * G * (2 * radius + 1) * H * W;
+    hipLaunchKernelGGL(igev_lookup_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, feat_pyramid,
+                       geo_pyramid, coords, out, a, G);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

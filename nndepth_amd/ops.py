@@ -237,3 +237,41 @@ class UpdateBlockEngine:
             check(lib.nnd_profile_conv(C.byref(self.desc), _p(self.packed), _p(ws), B, H, W, which, reps, _stream(d),
                                        C.byref(ms), C.byref(fl)), "profile_conv")
         return ms.value, fl.value
+
+
+# ------------------------------------------------------------------ IGEV geometry-encoding volume
+def group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, group_channels: int,
+                     num_levels: int) -> torch.Tensor:
+    """Group-wise 1-D correlation pyramid; layout = pyramid_layout(B*num_groups, H, W, num_levels)."""
+    d = _dev(fmap1, fmap2)
+    fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+    B, Ctot, H, W = fmap1.shape
+    _, _, total = pyramid_layout(B * num_groups, H, W, num_levels)
+    pyr = torch.empty(total, dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_group_corr_build(_p(fmap1), _p(fmap2), _p(pyr), B, Ctot, H, W, num_groups, group_channels,
+                                       num_levels, _stream(d)), "group_corr_build")
+    return pyr
+
+
+def pyramid_from_level0(level0: torch.Tensor, B: int, H: int, W: int, num_levels: int) -> torch.Tensor:
+    """level0: (B*H*W, W) rows -> full avg-pool pyramid buffer (levels 1..num_levels built on the device)."""
+    d = _dev(level0)
+    offs, widths, total = pyramid_layout(B, H, W, num_levels)
+    pyr = torch.empty(total, dtype=torch.float32, device=d)
+    pyr[:B * H * W * W].copy_(level0.reshape(-1))
+    with torch.cuda.device(d):
+        check(lib.nnd_pyramid_from_level0(_p(pyr), B, H, W, num_levels, _stream(d)), "pyramid_from_level0")
+    return pyr
+
+
+def igev_lookup(feat_pyr: torch.Tensor, geo_pyr: torch.Tensor, coords: torch.Tensor, num_groups: int,
+                num_levels: int, radius: int) -> torch.Tensor:
+    d = _dev(feat_pyr, geo_pyr, coords)
+    coords = coords.contiguous()
+    B, one, H, W = coords.shape
+    out = torch.empty((B, num_levels * 2 * num_groups * (2 * radius + 1), H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_igev_lookup(_p(feat_pyr), _p(geo_pyr), _p(coords), _p(out), B, num_groups, H, W, num_levels,
+                                  radius, _stream(d)), "igev_lookup")
+    return out

@@ -138,6 +138,40 @@ def main():
             cases[f"{name}_{k}"] = _np(v)
     np.savez_compressed(os.path.join(GOLD, "update_block.npz"), **cases)
 
+    # ------------------------------------- a12-a14: IGEV geometry-encoding volume (build, pyramids, lookup)
+    from nndepth.models.igev_stereo.cost_volume import GeometryAwareCostVolume, CostVolumeFilterNetwork
+    cases = {}
+    for name, (B, C, H, W) in {"g8_c128": (1, 128, 8, 24), "g8_c64_b2": (2, 64, 8, 32)}.items():
+        n = B * C * H * W
+        f1 = torch.from_numpy(weightgen.uniform01("if1" + name, n).reshape(B, C, H, W) * 2 - 1)
+        f2 = torch.from_numpy(weightgen.uniform01("if2" + name, n).reshape(B, C, H, W) * 2 - 1)
+        guides = [torch.from_numpy(weightgen.uniform01(f"ig{j}" + name, B * c * (H >> (j + 1)) * (W >> (j + 1))
+                                                       ).reshape(B, c, H >> (j + 1), W >> (j + 1)))
+                  for j, c in enumerate((40, 80, 160))]
+        reg = CostVolumeFilterNetwork(8, [40, 80, 160]).eval()
+        weightgen.fill_module_(reg, "igev.cv_regularizer.")
+        u = torch.from_numpy(weightgen.uniform01("ico" + name, B * H * W).reshape(B, 1, H, W))
+        coords = u * (W + 8) - 4
+        coords[:, :, 0, :] = torch.arange(W).float()
+        with torch.no_grad():
+            cv = GeometryAwareCostVolume(f1, f2, guides, reg, 4, 4, 8)
+            out = cv(coords)
+            fvol = R.group_corr_volume(f1, f2, 8)
+            gvol = reg(fvol.clone().permute(0, 1, 4, 2, 3), guides)
+            fp, gp = R.igev_pyramids(fvol, gvol, 4)
+            mine = R.igev_lookup(fp, gp, coords, 8, 4, 4)
+        report[f"igev/{name}"] = (max((a - b).abs().max().item() for a, b in zip(fp, cv.feat_corr_cv)),
+                                  max((a - b).abs().max().item() for a, b in zip(gp, cv.geo_aware_cv)),
+                                  (mine - out).abs().max().item())
+        cases[name + "_f1"], cases[name + "_f2"], cases[name + "_coords"] = _np(f1), _np(f2), _np(coords)
+        cases[name + "_out"] = _np(out)
+        cases[name + "_geo0"] = _np(cv.geo_aware_cv[0][:, 0])
+        for i in range(5):
+            cases[f"{name}_feat{i}"] = _np(cv.feat_corr_cv[i][:, 0])
+            if i:
+                cases[f"{name}_geo{i}"] = _np(cv.geo_aware_cv[i][:, 0])
+    np.savez_compressed(os.path.join(GOLD, "igev_volume.npz"), **cases)
+
     # ---------------------------------------------------------- a10: convex upsample
     cases = {}
     for name, (B, C, H, W, rate) in {"r8_c1": (2, 1, 6, 10, 8), "r4_c1": (1, 1, 7, 9, 4), "r8_c2": (1, 2, 5, 8, 8)}.items():

@@ -88,6 +88,47 @@ def corr1d_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, num_levels:
     return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
 
 
+# ----------------------------------------------------------- IGEV geometry-encoding volume
+def group_corr_volume(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int) -> torch.Tensor:
+    """nndepth/models/igev_stereo/cost_volume.py:81-98 — torch.split(fmap, num_groups) gives chunks of `num_groups`
+    CHANNELS; only the first `num_groups` chunks are correlated (Q4).  -> (B, G, H, W1, W2)."""
+    g1 = torch.split(fmap1, num_groups, dim=1)
+    g2 = torch.split(fmap2, num_groups, dim=1)
+    vols = []
+    for i in range(num_groups):
+        a, b = g1[i].permute(0, 2, 3, 1), g2[i].permute(0, 2, 1, 3)
+        vols.append(torch.matmul(a, b) / a.shape[-1] ** 0.5)
+    return torch.stack(vols, dim=1)
+
+
+def igev_pyramids(feat_vol: torch.Tensor, geo_vol: torch.Tensor, num_levels: int):
+    """igev_stereo/cost_volume.py:40-52.  feat_vol (B,G,H,W1,W2); geo_vol (B,G,W2,H,W1) as the regulariser returns
+    it.  -> two lists of num_levels+1 tensors (B*G*H*W1, 1, W2_l)."""
+    B, G, H, W1, W2 = feat_vol.shape
+    f = feat_vol.reshape(B * G * H * W1, 1, W2)
+    g = geo_vol.permute(0, 1, 3, 4, 2).reshape(B * G * H * W1, 1, W2)
+    fp, gp = [f], [g]
+    for _ in range(num_levels):
+        f, g = F.avg_pool1d(f, 2), F.avg_pool1d(g, 2)
+        fp.append(f)
+        gp.append(g)
+    return fp, gp
+
+
+def igev_lookup(fp, gp, coords: torch.Tensor, num_groups: int, num_levels: int, radius: int) -> torch.Tensor:
+    """igev_stereo/cost_volume.py:54-79 -> (B, L*2*G*(2r+1), H, W), channel = i*2GT + v*GT + g*T + k."""
+    B, _, H, W = coords.shape
+    outs = []
+    dx = torch.linspace(-radius, radius, 2 * radius + 1).reshape(1, -1)
+    for i in range(num_levels):
+        c = coords.permute(0, 2, 3, 1).unsqueeze(1).repeat(1, num_groups, 1, 1, 1)
+        x = c.reshape(B * num_groups * H * W, 1) / 2 ** i + dx
+        for pyr in (fp, gp):
+            s = linear_sampler(pyr[i].reshape(B * num_groups * H * W, -1), x)
+            outs.append(s.reshape(B, num_groups, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
 # ------------------------------------------------------------------------- update block
 def motion_encoder(sd: SD, p: str, flow: torch.Tensor, corr: torch.Tensor) -> torch.Tensor:
     """nndepth/blocks/update_block.py:57-65."""

@@ -296,3 +296,55 @@ def test_conv2d_generic_shapes():
             y = conv(x.to(DEV), relu=relu).cpu()
             exp = torch.relu(ref) if relu else ref
             assert (y - exp).abs().max() <= 2e-5, (Cout, Cin, KH, KW, B, H, W, relu)
+
+
+# ------------------------------------------------------------ IGEV geometry-encoding volume (a12-a14)
+@pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
+def test_igev_volume_golden(ops, gold, name, B, H, W):
+    g = gold("igev_volume.npz")
+    f1, f2, coords = (t(g[f"{name}_{k}"]).to(DEV) for k in ("f1", "f2", "coords"))
+    G = 8
+    # group-wise build + feature pyramid
+    feat = ops.group_corr_build(f1, f2, G, G, 4)
+    offs, widths, _ = ops.pyramid_layout(B * G, H, W, 4)
+    n = B * G * H * W
+    for i, (o, w) in enumerate(zip(offs, widths)):
+        assert np.abs(feat[o:o + n * w].view(n, w).cpu().numpy() - g[f"{name}_feat{i}"]).max() <= 2e-6, f"feat level {i}"
+    # pyramid of the regularised volume (level 0 = the reference's geo volume)
+    geo = ops.pyramid_from_level0(t(g[name + "_geo0"]).to(DEV), B * G, H, W, 4)
+    for i, (o, w) in enumerate(zip(offs, widths)):
+        assert np.array_equal(geo[o:o + n * w].view(n, w).cpu().numpy(), g[f"{name}_geo{i}"]), f"geo level {i}"
+    # combined lookup on the reference's own pyramids: bit-exact
+    ref_feat = torch.cat([t(g[f"{name}_feat{i}"]).reshape(-1) for i in range(5)]).to(DEV)
+    out = ops.igev_lookup(ref_feat, geo, coords, G, 4, 4)
+    assert np.array_equal(out.cpu().numpy(), g[name + "_out"])
+    # and end to end through the HIP-built feature pyramid
+    out2 = ops.igev_lookup(feat, geo, coords, G, 4, 4)
+    assert np.abs(out2.cpu().numpy() - g[name + "_out"]).max() <= 5e-6
+
+
+def test_igev_cost_volume_class_vs_oracle(R):
+    """Drop-in GeometryAwareCostVolume (ctor = build, attributes, __call__) with a Conv3d regulariser run by
+    PyTorch on the GPU, against the oracle using the same regulariser on the CPU."""
+    from nndepth_amd.cost_volume import GeometryAwareCostVolume
+    torch.manual_seed(11)
+    B, C, H, W, G = 1, 128, 8, 40, 8
+    f1, f2 = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    conv = torch.nn.Conv3d(G, G, 3, padding=1)
+
+    def reg(vol, feats):
+        return torch.nn.functional.leaky_relu(conv(vol)) + vol
+
+    coords = torch.arange(W).float()[None, None, None].repeat(B, 1, H, 1) - torch.rand(B, 1, H, W) * 12
+    with torch.no_grad():
+        fvol = R.group_corr_volume(f1, f2, G)
+        gvol = reg(fvol.clone().permute(0, 1, 4, 2, 3), None)
+        fp, gp = R.igev_pyramids(fvol, gvol, 4)
+        exp = R.igev_lookup(fp, gp, coords, G, 4, 4)
+        conv = conv.to(DEV)
+        cv = GeometryAwareCostVolume(f1.to(DEV), f2.to(DEV), None, reg, 4, 4, G)
+        got = cv(coords.to(DEV))
+    assert len(cv.geo_aware_cv) == 5 and tuple(cv.geo_aware_cv[0].shape) == (B * G * H * W, 1, W)
+    assert (cv.feat_corr_cv[0][:, 0].cpu() - fp[0][:, 0]).abs().max() <= 2e-5
+    assert (cv.geo_aware_cv[0][:, 0].cpu() - gp[0][:, 0]).abs().max() <= 5e-4  # MIOpen Conv3d vs oneDNN
+    assert tuple(got.shape) == (B, 576, H, W) and (got.cpu() - exp).abs().max() <= 5e-4

@@ -76,3 +76,20 @@ def test_spec_matches_module_and_weightgen_is_deterministic(raft_sd):
     # the aliased shortcut norm carries identical values under both names (residual_block.py:51)
     assert torch.equal(raft_sd["fnet.layer1.0.norm3.weight"], raft_sd["fnet.layer1.0.downsample.1.weight"])
     m.load_state_dict(raft_sd, strict=True)
+
+
+@pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
+def test_igev_volume_oracle(gold, name, B, H, W):
+    """a12-a14: group-wise volume (only the first 8 chunks of 8 channels, Q4), pyramids, combined lookup."""
+    g = gold("igev_volume.npz")
+    f1, f2, coords = (t(g[f"{name}_{k}"]) for k in ("f1", "f2", "coords"))
+    fvol = R.group_corr_volume(f1, f2, 8)
+    assert tuple(fvol.shape) == (B, 8, H, W, W)
+    geo_vol = t(g[name + "_geo0"]).reshape(B, 8, H, W, W).permute(0, 1, 4, 2, 3)  # as the regulariser returns it
+    fp, gp = R.igev_pyramids(fvol, geo_vol, 4)
+    for i in range(5):
+        assert np.array_equal(fp[i][:, 0].numpy(), g[f"{name}_feat{i}"]), i
+        assert np.array_equal(gp[i][:, 0].numpy(), g[f"{name}_geo{i}"]), i
+    out = R.igev_lookup(fp, gp, coords, 8, 4, 4)
+    assert tuple(out.shape) == (B, 576, H, W)
+    assert np.array_equal(out.numpy(), g[name + "_out"])
