@@ -156,6 +156,16 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
                            float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                            float* workspace, int B, int H, int W, int rate, int iters, void* stream);
 
+/* IGEV variant of the loop (nndepth/models/igev_stereo/model.py:148-158): lookup = nnd_igev_lookup over both
+ * pyramids, and — reference quirk Q5 — the update block and the convex upsample receive the ABSOLUTE coordinate
+ * coords1 = arange(W) + disp_init + sum(delta), not the disparity.  disp_init = the soft-argmin initial disparity
+ * (computed by the caller: Conv3d squeezer + softmax, PyTorch).  up_out / low_out hold coordinates accordingly.  */
+int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
+                           const float* feat_pyramid, const float* geo_pyramid, int num_groups, int num_levels, int radius,
+                           const float* net, const float* inp, const float* disp_init,
+                           float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
+                           float* workspace, int B, int H, int W, int rate, int iters, void* stream);
+
 /* ------------------------------------------------------------------------------ profiling
  * Times `reps` back-to-back launches of ONE hot-path conv (selected by `which`, see
  * nnd_conv_name) on `stream` with hipEvents recorded on that same stream and returns the

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
                 float* coords = const_cast<float*>(a.aux0);
                 float* hx_flow = const_cast<float*>(a.aux1);
                 const float cnew = coords[b * a.abs0 + pix] + v;
-                const float f = cnew - (float)x;
+                const float f = a.hidden ? cnew : cnew - (float)x;  // hidden != 0: absolute coordinates (IGEV)
                 a.out0[b * a.obs0 + pix] = v;
                 coords[b * a.abs0 + pix] = cnew;
                 a.out1[b * a.obs1 + pix] = f;

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
 
 // coords += delta; flow = coords - x  (model.py:134-135), mirrored into the GRU input buffer.
 __global__ void advance_kernel(float* __restrict__ coords, const float* __restrict__ delta, float* __restrict__ flow,
-                               float* __restrict__ hx_flow, long hx_bs, int B, int H, int W) {
+                               float* __restrict__ hx_flow, long hx_bs, int B, int H, int W, int absolute) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
@@ -165,15 +165,16 @@ __global__ void advance_kernel(float* __restrict__ coords, const float* __restri
     const long pix = idx % HW;
     const int x = (int)(pix % W);
     float cnew = coords[idx] + delta[idx];
-    float f = cnew - (float)x;
+    float f = absolute ? cnew : cnew - (float)x;
     coords[idx] = cnew;
     flow[idx] = f;
     hx_flow[b * hx_bs + pix] = f;
 }
 
 // coords = x (+ disp_init); flow = coords - x
+// absolute != 0 (IGEV, Q5): the update block and the upsample receive the coordinate itself, not coords - x
 __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict__ flow, float* __restrict__ hx_flow,
-                                   long hx_bs, const float* __restrict__ disp_init, int B, int H, int W) {
+                                   long hx_bs, const float* __restrict__ disp_init, int B, int H, int W, int absolute) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
@@ -181,7 +182,7 @@ __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict
     const long pix = idx % HW;
     const int x = (int)(pix % W);
     float c = (float)x + (disp_init ? disp_init[idx] : 0.f);
-    float f = c - (float)x;
+    float f = absolute ? c : c - (float)x;
     coords[idx] = c;
     flow[idx] = f;
     hx_flow[b * hx_bs + pix] = f;
@@ -194,6 +195,7 @@ static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
 struct IoOpt {
     int parity = -1;       // >= 0: last GRU q also writes hcopy[parity]; mask.0 reads it
     bool advance = false;  // flow_head.conv2 runs the fused coords/flow update
+    bool absolute = false; // ... and emits the coordinate itself as `flow` (IGEV)
 };
 
 static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*H*W*/, float* mask_dst, float* delta_dst,
@@ -235,6 +237,7 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
                 io.out1 = act(w.flow, n, 1);
                 io.aux0 = act(w.coords, n, 1);
                 io.aux1 = act(w.hx + (hxC - 1) * n, hxC * n, 1);
+                io.hidden = opt.absolute ? 1 : 0;
             }
             break;
         case C_M2:
@@ -444,16 +447,21 @@ int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* pac
     return NND_OK;
 }
 
+// geo_pyramid != nullptr selects the IGEV variant: combined two-volume lookup over `groups` groups and
+// absolute coordinates into the update block / upsample (igev_stereo/model.py:152-158).
 static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
                           int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
                           int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W,
-                          int rate, int iters, void* stream) {
+                          int rate, int iters, void* stream, const float* geo_pyramid = nullptr, int groups = 1) {
     Plan p;
     int rc = make_plan(desc, &p);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && pyramid && net && inp && up_out && workspace, "raft_stereo_refine: null pointer");
     NND_REQUIRE(p.d.flow_channels == 1, "raft_stereo_refine: flow_channels must be 1");
-    NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1), "raft_stereo_refine: cor_planes %d != levels*(2r+1)", p.d.cor_planes);
+    const bool igev = geo_pyramid != nullptr;
+    NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1) * (igev ? 2 * groups : 1),
+                "refine: cor_planes %d does not match levels*(2r+1)%s", p.d.cor_planes, igev ? "*2*groups" : "");
+
     NND_REQUIRE(p.d.mask_channels == 9 * rate * rate, "raft_stereo_refine: mask_channels %d != 9*rate^2", p.d.mask_channels);
     NND_REQUIRE(B > 0 && H > 0 && W > 0 && iters > 0, "raft_stereo_refine: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -465,16 +473,22 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     NND_TRY(copy_slice(w.hx + hid * n, hxC * n, inp, ctx * n, ctx * n, B, s));
     float* hx_flow = w.hx + (hxC - 1) * n;
     const unsigned eg = (unsigned)cdiv64((int64_t)B * n, 256);
-    hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H, W);
+    hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H, W,
+                       igev ? 1 : 0);
     NND_LAUNCH_CHECK();
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
+    auto lookup = [&](hipStream_t st_) -> int {
+        if (igev) return nnd_igev_lookup(pyramid, geo_pyramid, w.coords, w.corr, B, groups, H, W, num_levels, radius, st_);
+        return corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, st_);
+    };
     static const bool single = getenv("NND_SINGLE_STREAM") != nullptr;
     Streams* st = single ? nullptr : side_streams();
     if (!st) {  // plain in-order version (also the debugging reference for the DAG below)
         for (int it = 0; it < iters; ++it) {
-            NND_TRY(corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, s));
+            NND_TRY(lookup(s));
             NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
-            hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W);
+            hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W,
+                               igev ? 1 : 0);
             NND_LAUNCH_CHECK();
             NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s));
         }
@@ -494,11 +508,12 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             IoOpt opt;
             opt.parity = it & 1;
             opt.advance = true;
+            opt.absolute = igev;
             NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
             NND_TRY(run_convf1(p, packed, w.flow, (int64_t)n, w.f1, B, H, W, st->a));
             NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
             NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
-            NND_TRY(corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, s));
+            NND_TRY(lookup(s));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
             NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
@@ -655,6 +670,15 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
     hit->stamp = ++clock_;
     NND_HIP_CHECK(hipGraphLaunch(hit->exec, (hipStream_t)stream));
     return NND_OK;
+}
+
+int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* feat_pyramid,
+                           const float* geo_pyramid, int num_groups, int num_levels, int radius, const float* net, const float* inp,
+                           const float* disp_init, float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
+                           float* workspace, int B, int H, int W, int rate, int iters, void* stream) {
+    NND_REQUIRE(geo_pyramid && num_groups > 0, "igev_stereo_refine: geometry pyramid / groups missing");
+    return enqueue_refine(desc, packed, feat_pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
+                          net_out, workspace, B, H, W, rate, iters, stream, geo_pyramid, num_groups);
 }
 
 int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const float* flow, float* out, int B, int Cin, int H,

@@ -220,6 +220,28 @@ class UpdateBlockEngine:
                                              _p(ws), B, H, W, rate, iters, _stream(d)), "raft_stereo_refine")
         return up, low, net_out
 
+    def refine_igev(self, feat_pyr, geo_pyr, num_groups: int, num_levels: int, radius: int, net, inp, rate: int,
+                    iters: int, disp_init=None, keep_all: bool = True):
+        """IGEV loop (absolute coordinates, combined lookup) -> (up, low, net) like refine()."""
+        if self.packed is None:
+            raise NndError("UpdateBlockEngine: parameters not loaded")
+        d = _dev(feat_pyr, geo_pyr, net, inp, self.packed)
+        net, inp = net.contiguous(), inp.contiguous()
+        B, _, H, W = net.shape
+        n_up = iters if keep_all else 1
+        up = torch.empty((n_up, B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
+        low = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+        net_out = torch.empty_like(net)
+        ws = self.workspace(B, H, W, d)
+        stride = up[0].numel() if keep_all else 0
+        if disp_init is not None:
+            disp_init = disp_init.contiguous()
+        with torch.cuda.device(d):
+            check(lib.nnd_igev_stereo_refine(C.byref(self.desc), _p(self.packed), _p(feat_pyr), _p(geo_pyr), num_groups,
+                                             num_levels, radius, _p(net), _p(inp), _p(disp_init), _p(up), stride, _p(low),
+                                             _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "igev_stereo_refine")
+        return up, low, net_out
+
     # ---- profiling (bench.py roofline)
     def conv_names(self) -> List[str]:
         n = lib.nnd_num_convs(C.byref(self.desc))

@@ -210,6 +210,20 @@ def raft_stereo_forward(sd: SD, frame1: torch.Tensor, frame2: torch.Tensor, iter
     return (ups, lows) if return_lowres else ups
 
 
+def igev_refine(sd: SD, p: str, fp, gp, net, inp, init_disp, iters: int, num_groups=8, num_levels=4, radius=4, rate=4):
+    """nndepth/models/igev_stereo/model.py:148-158: coords1 = arange + init; the update block and the upsample take the
+    ABSOLUTE coords1 (Q5).  -> list of up (B,1,rate*H,rate*W)."""
+    B, _, H, W = net.shape
+    coords1 = torch.arange(W).float()[None, None, None, :].repeat(B, 1, H, 1) + init_disp
+    ups = []
+    for _ in range(iters):
+        samp = igev_lookup(fp, gp, coords1, num_groups, num_levels, radius)
+        net, mask, delta = update_block(sd, p, net, inp, samp, coords1)
+        coords1 = coords1 + delta
+        ups.append(convex_upsample(coords1, mask, rate))
+    return ups
+
+
 def epe(disp_gt: torch.Tensor, disp_pred: torch.Tensor, max_flow: float = 1000.0) -> float:
     """nndepth/models/raft_stereo/scripts/evaluate.py:62-83 for equal-size inputs."""
     e = torch.sum((disp_pred - disp_gt) ** 2, dim=1).sqrt()

@@ -348,3 +348,35 @@ def test_igev_cost_volume_class_vs_oracle(R):
     assert (cv.feat_corr_cv[0][:, 0].cpu() - fp[0][:, 0]).abs().max() <= 2e-5
     assert (cv.geo_aware_cv[0][:, 0].cpu() - gp[0][:, 0]).abs().max() <= 5e-4  # MIOpen Conv3d vs oneDNN
     assert tuple(got.shape) == (B, 576, H, W) and (got.cpu() - exp).abs().max() <= 5e-4
+
+
+def test_igev_refine_loop_vs_oracle(R):
+    """a16 (loop part): IGEV refinement — combined lookup, hidden 64 / cor_planes 576 update block, absolute
+    coordinates into the update block and the rate-4 upsample (Q5) — one C-ABI call vs the oracle."""
+    from nndepth_amd import weightgen, ops
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.cost_volume import GeometryAwareCostVolume
+    torch.manual_seed(21)
+    B, C, H, W, G, iters = 1, 128, 16, 40, 8, 3
+    f1, f2 = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    net, inp = torch.tanh(torch.randn(B, 64, H, W)), torch.relu(torch.randn(B, 64, H, W))
+    init = -torch.rand(B, 1, H, W) * 6
+    sd = weightgen.fill_state_dict(R.update_block_spec("update_block", 64, 576, 64, 1, 4))
+    conv = torch.nn.Conv3d(G, G, 3, padding=1)
+
+    def reg(vol, feats):
+        return torch.nn.functional.leaky_relu(conv(vol)) + vol
+
+    with torch.no_grad():
+        fvol = R.group_corr_volume(f1, f2, G)
+        fp, gp = R.igev_pyramids(fvol, reg(fvol.clone().permute(0, 1, 4, 2, 3), None), 4)
+        exp = R.igev_refine(sd, "update_block", fp, gp, net, inp, init, iters)
+        # feed the oracle's geometry volume so the comparison isolates the HIP path from MIOpen's Conv3d
+        cv = GeometryAwareCostVolume(f1.to(DEV), f2.to(DEV), None, lambda v, f: gp[0].view(B, G, H, W, W).permute(0, 1, 4, 2, 3).to(DEV), 4, 4, G)
+        ub = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4)
+        ub.load_state_dict({k[len("update_block."):]: v for k, v in sd.items()})
+        eng = ub.to(DEV).sync_engine(DEV)
+        up, low, _ = eng.refine_igev(cv._feat, cv._geo, G, 4, 4, net.to(DEV), inp.to(DEV), 4, iters, disp_init=init.to(DEV))
+    for i in range(iters):
+        err = (up[i].cpu() - exp[i]).abs().max().item()
+        assert err <= 2e-4 * max(1.0, exp[i].abs().max().item() / 40), f"iter {i}: {err}"
