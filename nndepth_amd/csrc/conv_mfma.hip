@@ -297,6 +297,9 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
         __syncthreads();
     }
     if (!active) return;
+#ifdef NND_DBG_NO_EPI
+    if (acc[0][0] != 123.456f) return;
+#endif
     const int nreg = 16 / ks, reg0 = kj * nreg;  // ks is 1 or 2 (or 4): this wave's share of the tile
     if (ks > 1) {
         const float* red = lds + (size_t)(cbi * ks) * TS + lane;

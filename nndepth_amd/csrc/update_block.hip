@@ -22,16 +22,17 @@
 namespace nnd {
 
 // ------------------------------------------------------------------------------------ plan
-enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1, C_Q1, C_ZR2, C_Q2, C_FH1, C_M0, C_FC2, C_M2, C_COUNT };
+enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1, C_Q1, C_ZR2, C_Q2, C_FH1, C_M0, C_M2, C_COUNT };
 static const char* kConvNames[C_COUNT] = {"encoder.convc1",        "encoder.convc2", "encoder.convf2", "encoder.conv",
                                           "gru.convz1+convr1",     "gru.convq1",     "gru.convz2+convr2", "gru.convq2",
-                                          "flow_head.conv1", "mask.0", "flow_head.conv2", "mask.2"};
+                                          "flow_head.conv1", "mask.0", "mask.2"};
 
 struct Plan {
     nnd_update_block_desc d;
     bool sep;
     ConvLayer L[C_COUNT];
     int64_t f1_w, f1_b;  // raw encoder.convf1 weights [128][fc][49] + bias [128]
+    int64_t fc2_w, fc2_b;  // raw flow_head.conv2 weights [fc][hid][9] + bias [fc] (VALU kernel)
     int64_t total;
 };
 
@@ -78,7 +79,8 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     }
     p->L[C_FH1] = mk(3, 3, hid, hid, &off);
     p->L[C_M0] = mk(3, 3, hid, 2 * hid, &off);
-    p->L[C_FC2] = mk(3, 3, hid, fc, &off);
+    p->fc2_w = off; off += (int64_t)fc * hid * 9;
+    p->fc2_b = off; off += 4;  // keep 16-B alignment of what follows
     p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off);
     p->total = off;
     return NND_OK;
@@ -188,6 +190,71 @@ __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict
     hx_flow[b * hx_bs + pix] = f;
 }
 
+// flow_head.conv2: 3x3, hid -> FC (1 or 2) outputs.  One output channel wastes 31/32 of an MFMA tile, so this is a
+// VALU kernel: a workgroup stages the 6x10 halo patch of all `hid` channels of a 4x8 pixel tile in LDS, thread
+// (slice, px) accumulates hid/8 channels x 9 taps, the 8 slices are summed through LDS.  With `advance` the
+// recurrence update of nndepth/models/raft_stereo/model.py:134-135 is fused in: coords += delta; flow = coords - x
+// (or the coordinate itself for IGEV, `absolute`), mirrored into the GRU input buffer.
+template <int FC>
+__global__ void __launch_bounds__(256) flow_head2_kernel(const float* __restrict__ x, long xbs, int hid, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ delta,
+                                                         float* __restrict__ coords, float* __restrict__ flow,
+                                                         float* __restrict__ hx_flow, long hx_bs, int H, int W, int tiles_x,
+                                                         int advance, int absolute) {
+    extern __shared__ float sm[];
+    float* patch = sm;                 // [hid][60]
+    float* wl = sm + hid * 60;         // [FC][hid][9]
+    float* part = wl + FC * hid * 9;   // [8][FC][32]
+    const int tid = threadIdx.x;
+    const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
+    const long HW = (long)H * W;
+    const float* src = x + b * xbs;
+    for (int e = tid; e < hid * 60; e += 256) {
+        const int ci = e / 60, pos = e % 60;
+        const int gy = ty0 + pos / 10 - 1, gx = tx0 + pos % 10 - 1;
+        patch[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[ci * HW + (long)gy * W + gx] : 0.f;
+    }
+    for (int e = tid; e < FC * hid * 9; e += 256) wl[e] = w[e];
+    __syncthreads();
+    const int px = tid & 31, slice = tid >> 5;
+    const int r = px >> 3, c = px & 7;
+    const int cps = hid / 8;
+    float acc[FC];
+#pragma unroll
+    for (int f = 0; f < FC; ++f) acc[f] = 0.f;
+    for (int ci = slice * cps; ci < (slice + 1) * cps; ++ci) {
+        const float* pp = patch + ci * 60 + r * 10 + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = pp[(t / 3) * 10 + t % 3];
+#pragma unroll
+            for (int f = 0; f < FC; ++f) acc[f] = fmaf(wl[(f * hid + ci) * 9 + t], v, acc[f]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FC; ++f) part[(slice * FC + f) * 32 + px] = acc[f];
+    __syncthreads();
+    if (tid < 32 * FC) {
+        const int f = tid >> 5, p2 = tid & 31;
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) sum += part[(sl * FC + f) * 32 + p2];
+        sum += bias[f];
+        const int y = ty0 + (p2 >> 3), xx = tx0 + (p2 & 7);
+        if (y < H && xx < W) {
+            const long pix = (long)y * W + xx;
+            delta[(b * FC + f) * HW + pix] = sum;
+            if (advance) {  // FC == 1 on this path
+                const float cnew = coords[b * HW + pix] + sum;
+                const float fl = absolute ? cnew : cnew - (float)xx;
+                coords[b * HW + pix] = cnew;
+                flow[b * HW + pix] = fl;
+                hx_flow[b * hx_bs + pix] = fl;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ sequencing
 static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
 
@@ -230,16 +297,6 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.src0 = opt.parity >= 0 ? act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid) : act(w.hx, hxC * n, hid);
             io.out0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
             break;
-        case C_FC2:
-            io.src0 = act(w.fm, 3 * hid * n, hid);
-            io.out0 = act(delta_dst, fc * n, fc);
-            if (opt.advance) {
-                io.out1 = act(w.flow, n, 1);
-                io.aux0 = act(w.coords, n, 1);
-                io.aux1 = act(w.hx + (hxC - 1) * n, hxC * n, 1);
-                io.hidden = opt.absolute ? 1 : 0;
-            }
-            break;
         case C_M2:
             io.src0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
             io.out0 = act(mask_dst, p.d.mask_channels * n, p.d.mask_channels);
@@ -250,11 +307,9 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
 }
 
 static int conv_epi(int id, IoOpt opt = IoOpt()) {
-    if (id == C_FC2 && opt.advance) return EPI_ADVANCE;
     switch (id) {
         case C_ZR1: case C_ZR2: return EPI_GRU_ZR;
         case C_Q1: case C_Q2: return EPI_GRU_Q;
-        case C_FC2: return EPI_LINEAR;
         case C_M2: return EPI_SCALE;
         default: return EPI_RELU;
     }
@@ -291,6 +346,26 @@ static int run_convf1(const Plan& p, const float* blob, const float* flow, int64
         hipLaunchKernelGGL(convf1_kernel<2>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x);
     NND_LAUNCH_CHECK();
     return debug_sync("encoder.convf1", s);
+}
+
+static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta_dst, bool advance, bool absolute, int B, int H,
+                   int W, hipStream_t s) {
+    const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels, hxC = 2 * hid + ctx;
+    const int64_t n = (int64_t)H * W;
+    const int tiles_x = cdiv(W, 8);
+    dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(256);
+    const size_t lds = (size_t)(hid * 60 + fc * hid * 9 + 8 * fc * 32) * sizeof(float);
+    NND_REQUIRE(hid % 8 == 0 && lds <= 64 * 1024, "flow_head.conv2: hidden_dim %d not supported", hid);
+    NND_REQUIRE(!advance || fc == 1, "flow_head.conv2: fused advance needs flow_channels == 1");
+    float* hx_flow = w.hx + (hxC - 1) * n;
+    if (fc == 1)
+        hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance ? 1 : 0, absolute ? 1 : 0);
+    else
+        hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, 0, 0);
+    NND_LAUNCH_CHECK();
+    return debug_sync("flow_head.conv2", s);
 }
 
 // Side streams + events for the fused loop.  Created once per device on first use (the only mutable global
@@ -343,7 +418,7 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
         NND_TRY(run_conv(p, blob, w, C_Q2, corr, nullptr, nullptr, B, H, W, s));
     }
     NND_TRY(run_conv(p, blob, w, C_FH1, corr, nullptr, nullptr, B, H, W, s));
-    NND_TRY(run_conv(p, blob, w, C_FC2, corr, nullptr, delta_dst, B, H, W, s));
+    NND_TRY(run_fc2(p, blob, w, delta_dst, false, false, B, H, W, s));
     if (mask_dst) {
         NND_TRY(run_conv(p, blob, w, C_M0, corr, nullptr, nullptr, B, H, W, s));
         NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
@@ -412,7 +487,8 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
     }
     one(C_FH1, k);
     one(C_M0, k + 4);
-    one(C_FC2, k + 2);
+    memcpy(out + p.fc2_w, t[k + 2], sizeof(float) * fc * hid * 9);
+    memcpy(out + p.fc2_b, t[k + 3], sizeof(float) * fc);
     one(C_M2, k + 6);
     return NND_OK;
 }
@@ -530,7 +606,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, st->b));
             NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
             if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
-            NND_TRY(run_conv(p, packed, w, C_FC2, c, nullptr, w.delta, B, H, W, s, opt));
+            NND_TRY(run_fc2(p, packed, w, w.delta, true, igev, B, H, W, s));
             NND_HIP_CHECK(hipEventRecord(st->adv, s));
             NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
             if (fused_up)  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM

@@ -1,0 +1,27 @@
+"""Summarise a rocprofv3 --kernel-trace csv of bench.py: per (kernel, grid) durations inside the loop, main-stream gaps."""
+import csv, glob, re, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(n):
+    m = re.search(r"conv_mfma_kernel<([^>]*)>", n)
+    if m: return "conv<" + m.group(1).replace(" ", "") + ">"
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n[:30]
+idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
+i0 = idx[-1]
+last = max(i for i, r in enumerate(rows) if "mask_upsample" in r["Kernel_Name"] or "convex_upsample" in r["Kernel_Name"])
+seq = [r for r in rows[i0:last + 1] if "nnd::" in r["Kernel_Name"]]
+mq = [r["Queue_Id"] for r in seq if "lookup" in r["Kernel_Name"]][0]
+g = collections.OrderedDict()
+for r in seq:
+    k = (("M " if r["Queue_Id"] == mq else "s ") + short(r["Kernel_Name"]), r["Grid_Size_X"])
+    g.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+tot_main = 0
+for k, v in g.items():
+    print(f"{k[0]:34s} grid {k[1]:>7s} n {len(v):4d} avg {sum(v)/len(v):7.1f} us  sum {sum(v)/1e3:7.2f} ms")
+    if k[0].startswith("M "): tot_main += sum(v)
+main = [r for r in seq if r["Queue_Id"] == mq]
+gaps = sum(max(0, int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) for a, b in zip(main[:-1], main[1:])) / 1e3
+span = (int(main[-1]["End_Timestamp"]) - int(main[0]["Start_Timestamp"])) / 1e3
+print(f"main stream: span {span/1e3:.2f} ms, kernels {tot_main/1e3:.2f} ms, gaps {gaps/1e3:.2f} ms")
