@@ -74,6 +74,7 @@ struct ConvIO {
     Act src0, src1;      // virtual concat [src0, src1] along channels (src1.C may be 0)
     Act out0, out1;      // see ConvEpilogue
     Act aux0, aux1;
+    Act bmap;            // optional per-pixel bias map (replaces the per-channel bias)
     int hidden = 0;
     float scale = 1.f;
 };
@@ -87,7 +88,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
 // Host-side packing of one (virtually concatenated along Cout) conv into A-fragment order.
 // w[i]: (cout[i], Cin, KH, KW) row-major, b[i]: (cout[i]).
 void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const float* const* b,
-               const int* cout, float* blob);
+               const int* cout, float* blob, const int* ci_map = nullptr, int cin_src = 0);
 
 // corr1d.hip
 int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,

@@ -61,6 +61,8 @@ struct ConvArgs {
     const float* aux0;
     const float* aux1;
     long abs0, abs1;
+    const float* bmap;  // optional per-pixel bias (B, Cout, H, W) added instead of bias[co]
+    long bmbs;
     int H, W, Cout, nchunks, epi, hidden;
     int tiles_x, wco, ks, npos, ngroups;
     float scale;
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-        bias_r[reg] = (reg >= reg0 && reg < reg0 + nreg && co < a.Cout) ? a.bias[co] : 0.f;
+        bias_r[reg] = (!a.bmap && reg >= reg0 && reg < reg0 + nreg && co < a.Cout) ? a.bias[co] : 0.f;
     }
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) {
@@ -330,6 +332,14 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
         const bool pix_ok = (y < H && x < W);
         const long pix = pix_ok ? (long)y * W + x : 0;
         float h_r[16], z_r[16];
+        if (a.bmap) {  // precomputed context term of the GRU convs (constant over the iterations of a pair)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
+                bias_r[reg] = ok ? a.bmap[b * a.bmbs + co * HW + pix] : 0.f;
+            }
+        }
         if (epi == EPI_GRU_ZR || epi == EPI_GRU_Q) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -487,6 +497,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.out1 = io.out1.ptr; a.obs1 = io.out1.bstride;
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
+    a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks;
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;
@@ -511,8 +522,12 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
 // input channels per K-chunk for a layer shape (the host packer and the kernels must agree)
 int conv_ci_t(int KH, int KW, int Cin) { return (KH == 1 && KW == 1 && Cin >= 128) ? 128 : 32; }
 
+// The packed layer may take only a subset of the source tensor's input channels: packed channel ci reads source
+// channel ci_map[ci] of a (cout, cin_src, KH, KW) tensor (ci_map == nullptr: identity, cin_src = L.Cin).
+// bvec[part] == nullptr packs a zero bias (the caller adds it elsewhere).
 void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const float* const* bvec,
-               const int* cout, float* blob) {
+               const int* cout, float* blob, const int* ci_map, int cin_src) {
+    if (!ci_map) cin_src = L.Cin;
     const int NT = L.KH * L.KW, NQ = L.CI_T / 8;
     float* wp = blob + L.w_off;
     float* bp = blob + L.b_off;
@@ -525,7 +540,7 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
         for (int col = 0; col < cout[part]; ++col) {
             int co = co0 + col;
             int cb = co / 32, i = co % 32;
-            bp[co] = bvec[part][col];
+            bp[co] = bvec[part] ? bvec[part][col] : 0.f;
             for (int ci = 0; ci < L.Cin; ++ci) {
                 int chunk = ci / L.CI_T, cl = ci % L.CI_T;
                 int pair = cl / 2, h2 = cl % 2;
@@ -533,7 +548,7 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
                 int lane = h2 * 32 + i;
                 for (int t = 0; t < NT; ++t) {
                     size_t idx = (((((size_t)cb * L.nchunks + chunk) * NT + t) * NQ + q) * 64 + lane) * 4 + j;
-                    wp[idx] = w[part][((size_t)col * L.Cin + ci) * NT + t];
+                    wp[idx] = w[part][((size_t)col * cin_src + (ci_map ? ci_map[ci] : ci)) * NT + t];
                 }
             }
         }

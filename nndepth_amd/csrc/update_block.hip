@@ -22,10 +22,16 @@
 namespace nnd {
 
 // ------------------------------------------------------------------------------------ plan
-enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1, C_Q1, C_ZR2, C_Q2, C_FH1, C_M0, C_M2, C_COUNT };
-static const char* kConvNames[C_COUNT] = {"encoder.convc1",        "encoder.convc2", "encoder.convf2", "encoder.conv",
-                                          "gru.convz1+convr1",     "gru.convq1",     "gru.convz2+convr2", "gru.convq2",
-                                          "flow_head.conv1", "mask.0", "mask.2"};
+// C_*X: GRU convs of the fused loop — input = [h | motion+flow] only; the contribution of the context features
+// `inp` (constant over the iterations of a pair) is precomputed once per pair by the C_*C convs and enters as a
+// per-pixel bias map.  C_ZR1..C_Q2 are the full convs used by the single-call API (nnd_update_block_forward).
+enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1X, C_Q1X, C_ZR2X, C_Q2X, C_FH1, C_M0, C_M2, C_LOOP_COUNT,
+              C_ZR1 = C_LOOP_COUNT, C_Q1, C_ZR2, C_Q2, C_ZR1C, C_Q1C, C_ZR2C, C_Q2C, C_COUNT };
+static const char* kConvNames[C_COUNT] = {"encoder.convc1", "encoder.convc2", "encoder.convf2", "encoder.conv",
+                                          "gru.convz1+convr1[h,motion]", "gru.convq1[rh,motion]", "gru.convz2+convr2[h,motion]",
+                                          "gru.convq2[rh,motion]", "flow_head.conv1", "mask.0", "mask.2",
+                                          "gru.convz1+convr1", "gru.convq1", "gru.convz2+convr2", "gru.convq2",
+                                          "gru.convz1+convr1[inp]", "gru.convq1[inp]", "gru.convz2+convr2[inp]", "gru.convq2[inp]"};
 
 struct Plan {
     nnd_update_block_desc d;
@@ -66,17 +72,21 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->f1_b = off; off += 128;
     p->L[C_F2] = mk(3, 3, 128, 64, &off);
     p->L[C_CV] = mk(3, 3, 256, hid - fc, &off);
-    if (p->sep) {
-        p->L[C_ZR1] = mk(1, 5, gin, 2 * hid, &off);
-        p->L[C_Q1] = mk(1, 5, gin, hid, &off);
-        p->L[C_ZR2] = mk(5, 1, gin, 2 * hid, &off);
-        p->L[C_Q2] = mk(5, 1, gin, hid, &off);
-    } else {
-        p->L[C_ZR1] = mk(3, 3, gin, 2 * hid, &off);
-        p->L[C_Q1] = mk(3, 3, gin, hid, &off);
-        p->L[C_ZR2] = p->L[C_ZR1];
-        p->L[C_Q2] = p->L[C_Q1];
+    for (int pass = 0; pass < (p->sep ? 2 : 1); ++pass) {
+        const int kh = p->sep ? (pass == 0 ? 1 : 5) : 3, kw = p->sep ? (pass == 0 ? 5 : 1) : 3;
+        const int zr = pass == 0 ? C_ZR1 : C_ZR2, q = pass == 0 ? C_Q1 : C_Q2;
+        p->L[zr] = mk(kh, kw, gin, 2 * hid, &off);
+        p->L[q] = mk(kh, kw, gin, hid, &off);
+        p->L[zr - C_ZR1 + C_ZR1X] = mk(kh, kw, 2 * hid, 2 * hid, &off);
+        p->L[q - C_ZR1 + C_ZR1X] = mk(kh, kw, 2 * hid, hid, &off);
+        p->L[zr - C_ZR1 + C_ZR1C] = mk(kh, kw, ctx, 2 * hid, &off);
+        p->L[q - C_ZR1 + C_ZR1C] = mk(kh, kw, ctx, hid, &off);
     }
+    if (!p->sep)
+        for (int base : {(int)C_ZR1X, (int)C_ZR1, (int)C_ZR1C}) {
+            p->L[base + 2] = p->L[base];
+            p->L[base + 3] = p->L[base + 1];
+        }
     p->L[C_FH1] = mk(3, 3, hid, hid, &off);
     p->L[C_M0] = mk(3, 3, hid, 2 * hid, &off);
     p->fc2_w = off; off += (int64_t)fc * hid * 9;
@@ -88,7 +98,7 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
 
 // ------------------------------------------------------------------------------- workspace
 struct Bufs {
-    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow, *hcopy;
+    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow, *hcopy, *ctxb;
     int64_t total;
 };
 
@@ -114,6 +124,7 @@ static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
     b->coords = take(1);
     b->flow = take(fc);
     b->hcopy = take(2 * hid);  // double-buffered copy of h for the mask branch (side stream)
+    b->ctxb = take(6 * hid);   // context terms of the GRU convs: [zr1 2h | q1 h | zr2 2h | q2 h]
     b->total = off;
 }
 
@@ -292,6 +303,37 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.aux1 = act(w.z, hid * n, hid);
             if (opt.parity >= 0 && id == (p.sep ? C_Q2 : C_Q1)) io.out1 = act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid);
             break;
+        case C_ZR1X:
+        case C_ZR2X: {  // [h | motion+flow] + context bias map
+            io.src0 = act(w.hx, hxC * n, hid);
+            io.src1 = act(w.hx + (hid + ctx) * n, hxC * n, hid);
+            io.out0 = act(w.z, hid * n, hid);
+            io.out1 = act(w.rh, hid * n, hid);
+            io.aux0 = act(w.hx, hxC * n, hid);
+            io.bmap = act(w.ctxb + (id == C_ZR1X ? 0 : 3 * hid) * n, 6 * hid * n, 2 * hid);
+            io.hidden = hid;
+            break;
+        }
+        case C_Q1X:
+        case C_Q2X:
+            io.src0 = act(w.rh, hid * n, hid);
+            io.src1 = act(w.hx + (hid + ctx) * n, hxC * n, hid);
+            io.out0 = act(w.hx, hxC * n, hid);
+            io.aux0 = act(w.hx, hxC * n, hid);
+            io.aux1 = act(w.z, hid * n, hid);
+            io.bmap = act(w.ctxb + (id == C_Q1X ? 2 * hid : 5 * hid) * n, 6 * hid * n, hid);
+            if (opt.parity >= 0 && id == (p.sep ? C_Q2X : C_Q1X)) io.out1 = act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid);
+            break;
+        case C_ZR1C:
+        case C_ZR2C:  // context term: conv over `inp` only (+ the conv's bias), linear
+            io.src0 = act(w.hx + hid * n, hxC * n, ctx);
+            io.out0 = act(w.ctxb + (id == C_ZR1C ? 0 : 3 * hid) * n, 6 * hid * n, 2 * hid);
+            break;
+        case C_Q1C:
+        case C_Q2C:
+            io.src0 = act(w.hx + hid * n, hxC * n, ctx);
+            io.out0 = act(w.ctxb + (id == C_Q1C ? 2 * hid : 5 * hid) * n, 6 * hid * n, hid);
+            break;
         case C_FH1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, hid); break;
         case C_M0:
             io.src0 = opt.parity >= 0 ? act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid) : act(w.hx, hxC * n, hid);
@@ -308,8 +350,9 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
 
 static int conv_epi(int id, IoOpt opt = IoOpt()) {
     switch (id) {
-        case C_ZR1: case C_ZR2: return EPI_GRU_ZR;
-        case C_Q1: case C_Q2: return EPI_GRU_Q;
+        case C_ZR1: case C_ZR2: case C_ZR1X: case C_ZR2X: return EPI_GRU_ZR;
+        case C_Q1: case C_Q2: case C_Q1X: case C_Q2X: return EPI_GRU_Q;
+        case C_ZR1C: case C_ZR2C: case C_Q1C: case C_Q2C: return EPI_LINEAR;
         case C_M2: return EPI_SCALE;
         default: return EPI_RELU;
     }
@@ -477,12 +520,35 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
     memcpy(out + p.f1_b, t[5], sizeof(float) * 128);
     one(C_F2, 6);
     one(C_CV, 8);
-    two(C_ZR1, 10, 12, hid, hid);
-    one(C_Q1, 14);
+    // GRU convs three ways: full (API path), [h | motion+flow] channels only (loop), `inp` channels only
+    // (per-pair context term, carries the bias).  Source channel order of the reference: [h | inp | motion+flow].
+    const int ctx = p.d.context_dim, gin = 2 * hid + ctx;
+    std::vector<int> map_x(2 * hid), map_c(ctx);
+    for (int i = 0; i < hid; ++i) {
+        map_x[i] = i;
+        map_x[hid + i] = hid + ctx + i;
+    }
+    for (int i = 0; i < ctx; ++i) map_c[i] = hid + i;
+    auto gru = [&](int pass, int tz, int tr, int tq) {
+        const int zr = pass == 0 ? C_ZR1 : C_ZR2, q = pass == 0 ? C_Q1 : C_Q2;
+        two(zr, tz, tr, hid, hid);
+        one(q, tq);
+        const float* wzr[2] = {t[tz], t[tr]};
+        const float* bzr[2] = {t[tz + 1], t[tr + 1]};
+        const float* nob[2] = {nullptr, nullptr};
+        int czr[2] = {hid, hid};
+        pack_conv(p.L[zr - C_ZR1 + C_ZR1X], 2, wzr, nob, czr, out, map_x.data(), gin);
+        pack_conv(p.L[zr - C_ZR1 + C_ZR1C], 2, wzr, bzr, czr, out, map_c.data(), gin);
+        const float* wq[1] = {t[tq]};
+        const float* bq[1] = {t[tq + 1]};
+        int cq[1] = {hid};
+        pack_conv(p.L[q - C_ZR1 + C_ZR1X], 1, wq, nob, cq, out, map_x.data(), gin);
+        pack_conv(p.L[q - C_ZR1 + C_ZR1C], 1, wq, bq, cq, out, map_c.data(), gin);
+    };
+    gru(0, 10, 12, 14);
     int k = 16;
     if (p.sep) {
-        two(C_ZR2, 16, 18, hid, hid);
-        one(C_Q2, 20);
+        gru(1, 16, 18, 20);
         k = 22;
     }
     one(C_FH1, k);
@@ -557,6 +623,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         if (igev) return nnd_igev_lookup(pyramid, geo_pyramid, w.coords, w.corr, B, groups, H, W, num_levels, radius, st_);
         return corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, st_);
     };
+    // per-pair context terms of the GRU convs (inp is constant over the iterations)
+    for (int id : {(int)C_ZR1C, (int)C_Q1C, (int)C_ZR2C, (int)C_Q2C})
+        if (p.sep || id < C_ZR2C) NND_TRY(run_conv(p, packed, w, id, c, nullptr, nullptr, B, H, W, s));
     static const bool single = getenv("NND_SINGLE_STREAM") != nullptr;
     Streams* st = single ? nullptr : side_streams();
     if (!st) {  // plain in-order version (also the debugging reference for the DAG below)
@@ -594,11 +663,11 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
             NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
             NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
-            NND_TRY(run_conv(p, packed, w, C_ZR1, c, nullptr, nullptr, B, H, W, s));
-            NND_TRY(run_conv(p, packed, w, C_Q1, c, nullptr, nullptr, B, H, W, s, opt));
+            NND_TRY(run_conv(p, packed, w, C_ZR1X, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(run_conv(p, packed, w, C_Q1X, c, nullptr, nullptr, B, H, W, s, opt));
             if (p.sep) {
-                NND_TRY(run_conv(p, packed, w, C_ZR2, c, nullptr, nullptr, B, H, W, s));
-                NND_TRY(run_conv(p, packed, w, C_Q2, c, nullptr, nullptr, B, H, W, s, opt));
+                NND_TRY(run_conv(p, packed, w, C_ZR2X, c, nullptr, nullptr, B, H, W, s));
+                NND_TRY(run_conv(p, packed, w, C_Q2X, c, nullptr, nullptr, B, H, W, s, opt));
             }
             NND_HIP_CHECK(hipEventRecord(st->q2, s));
             NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->q2, 0));
@@ -770,12 +839,12 @@ int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const flo
 int nnd_num_convs(const nnd_update_block_desc* desc) {
     Plan p;
     if (make_plan(desc, &p) != NND_OK) return NND_ERR_INVALID;
-    return C_COUNT;
+    return C_LOOP_COUNT;
 }
 
 const char* nnd_conv_name(const nnd_update_block_desc* desc, int which) {
     (void)desc;
-    return (which >= 0 && which < C_COUNT) ? kConvNames[which] : "";
+    return (which >= 0 && which < C_LOOP_COUNT) ? kConvNames[which] : "";
 }
 
 int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, float* workspace, int B, int H, int W, int which,
@@ -784,8 +853,8 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, flo
     int rc = make_plan(desc, &p);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && workspace && ms_out && flops_out, "profile_conv: null pointer");
-    NND_REQUIRE(which >= 0 && which < C_COUNT && reps > 0, "profile_conv: bad conv index / reps");
-    NND_REQUIRE(p.sep || (which != C_ZR2 && which != C_Q2), "profile_conv: conv_gru has no second GRU pass");
+    NND_REQUIRE(which >= 0 && which < C_LOOP_COUNT && reps > 0, "profile_conv: bad conv index / reps");
+    NND_REQUIRE(p.sep || (which != C_ZR2X && which != C_Q2X), "profile_conv: conv_gru has no second GRU pass");
     hipStream_t s = (hipStream_t)stream;
     Bufs w;
     carve(p, B, H, W, workspace, &w);
