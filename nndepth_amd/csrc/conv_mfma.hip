@@ -48,6 +48,20 @@ __host__ __device__ constexpr int patch_stride(int PC, int SC) {
     return s;
 }
 
+#ifdef NND_DBG_STAMPS
+// debug build only: per-workgroup phase timestamps (s_memrealtime, 100 MHz) for scripts/stamps.py
+__device__ unsigned long long g_stamps[4096 * 8];
+#define NND_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
+            if (lin_ < 4096) g_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();              \
+        }                                                                                              \
+    } while (0)
+#else
+#define NND_STAMP(i)
+#endif
+
 struct ConvArgs {
     const float* src0;
     const float* src1;
@@ -104,6 +118,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     constexpr int NB = SG / 2 * P;             // MFMAs (= B operands) per step
     constexpr int PH = KH / 2, PW = KW / 2;
     extern __shared__ float lds[];
+    NND_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar address math
@@ -207,6 +222,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     load_x(0);
     store_x(0);
     __syncthreads();
+    NND_STAMP(1);
 
     auto chunk = [&](int K, auto par_c) {
         constexpr int par = decltype(par_c)::value;
@@ -284,6 +300,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
         }
     }
 
+    NND_STAMP(2);
     // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier).
     // Every K-slice wave publishes its partial tile; slice kj then owns registers [kj*16/ks, (kj+1)*16/ks) of the
     // tile for the epilogue, so the gate math / stores of a tile are spread over all ks waves.
@@ -316,6 +333,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             }
     }
 
+    NND_STAMP(3);
     // ---- epilogue: lane holds pixel (y, x_pp) and 16 output channels.  All loads (bias, h, z) are issued
     // before any store: out0 may alias aux0 (GRU blend in place), which would otherwise serialise load/store.
     const int y = ty0 + r;
@@ -391,6 +409,10 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             }
         }
     }
+#ifdef NND_DBG_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    NND_STAMP(4);
 }
 
 // --------------------------------------------------------------------------- host side
@@ -556,4 +578,9 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
     }
 }
 
+#ifdef NND_DBG_STAMPS
+extern "C" int nnd_debug_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // namespace nnd
