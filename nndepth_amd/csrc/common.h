@@ -47,9 +47,7 @@ enum ConvEpilogue {
     EPI_GRU_ZR = 2,  // co <  hidden: out0[co] = sigmoid(v)                (z)
                      // co >= hidden: out1[co-hidden] = sigmoid(v) * aux0  (r*h)
     EPI_GRU_Q = 3,   // q = tanh(v); out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z); out1 (optional) = copy
-    EPI_SCALE = 4,   // out0 = scale * v
-    EPI_ADVANCE = 5  // Cout = 1: delta = v -> out0; coords (aux0, in/out) += delta; flow = coords - x -> out1 and aux1
-                     // (nndepth/models/raft_stereo/model.py:134-135 fused into flow_head.conv2)
+    EPI_SCALE = 4    // out0 = scale * v
 };
 
 // One convolution layer inside a packed parameter blob.
@@ -77,6 +75,8 @@ struct ConvIO {
     Act bmap;            // optional per-pixel bias map (replaces the per-channel bias)
     int hidden = 0;
     float scale = 1.f;
+    bool src_tiled = false;  // layout.h: sources are tile-major (internal workspace) instead of NCHW
+    bool dst_tiled = false;  // ... out0/out1/aux0/aux1/bmap
 };
 
 // input channels per K-chunk for a layer shape (host packer and kernels must agree)
@@ -91,14 +91,17 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
                const int* cout, float* blob, const int* ci_map = nullptr, int cin_src = 0);
 
 // corr1d.hip
+// `tiled`: coords / sampled features (resp. flow / mask) are tile-major workspace tensors (layout.h), else NCHW
 int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,
-                         int radius, hipStream_t stream);
+                         int radius, hipStream_t stream, bool tiled);
+int igev_lookup_launch(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
+                       int W, int num_levels, int radius, hipStream_t stream, bool tiled);
 int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
-                           hipStream_t stream);
+                           hipStream_t stream, bool tiled);
 
 // mask_upsample.hip: fused mask.2 (1x1, x0.25) + softmax + convex upsample (mask never written)
 bool mask_upsample_supported(int rate, int cin, int flow_channels);
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream);
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled);
 
 }  // namespace nnd

@@ -24,6 +24,7 @@
 // Replaces the nn.Conv2d calls of nndepth/blocks/update_block.py:57-65,26-36,97-112 and
 // nndepth/blocks/gru.py:22-37,53-61 (reference files; semantics restated in oracle/torch_ref.py).
 #include "common.h"
+#include "layout.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -77,6 +78,7 @@ struct ConvArgs {
     long abs0, abs1;
     const float* bmap;  // optional per-pixel bias (B, Cout, H, W) added instead of bias[co]
     long bmbs;
+    Lay ls, ld;         // layout of the sources / of every destination-side tensor (out*, aux*, bmap)
     int H, W, Cout, nchunks, epi, hidden;
     int tiles_x, wco, ks, npos, ngroups;
     float scale;
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     const bool active = cb * 32 < a.Cout;  // trailing waves of the last workgroup only help staging
     const int b = blockIdx.z;
     const int H = a.H, W = a.W;
-    const long HW = (long)H * W;
+    const long SP = a.ls.plane, DP = a.ld.plane;  // channel strides of the source / destination tensors
     // LDS patch geometry is compile-time so every B-operand read is base + immediate offset.
     // Row stride S is an odd multiple of SC: lanes (r, c) then hit 32 distinct banks.
     constexpr int PR = SR + KH - 1, PC = P * SC + KW - 1;
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     const int pr = pos / PC, pc = pos - pr * PC;
     const int gy = ty0 + pr - PH, gx = tx0 + pc - PW;
     const bool inimg = stager && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const int goff0 = inimg ? gy * W + gx : 0;
+    const int goff0 = inimg ? (int)pix_off(a.ls, gy, gx) : 0;
     const int loff0 = pr * S + pc;
     const int trash = 2 * SCH * PATCH;  // one spare LDS word swallows the stores of non-staging threads
 
@@ -166,11 +168,11 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     auto chunk_src = [&](int K, const float*& src, int& climit) {
         int cbase = K * SCH;
         if (cbase < a.c0) {
-            src = a.src0 + b * a.bs0 + (long)cbase * HW;
+            src = a.src0 + b * a.bs0 + (long)cbase * SP;
             climit = a.c0 - cbase;
         } else {
             int cc = cbase - a.c0;
-            src = a.src1 + b * a.bs1 + (long)cc * HW;
+            src = a.src1 + b * a.bs1 + (long)cc * SP;
             climit = a.c1 - cc;
         }
     };
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int ci = cg + j * ngroups;
-            stage[j] = src[ci < climit ? (unsigned)(ci * (int)HW + goff0) : 0u];
+            stage[j] = src[ci < climit ? (unsigned)(ci * (int)SP + goff0) : 0u];
         }
     };
     auto store_x = [&](int K) {
@@ -348,14 +350,14 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
     for (int pp = 0; pp < P; ++pp) {
         const int x = tx0 + pp * SC + c;
         const bool pix_ok = (y < H && x < W);
-        const long pix = pix_ok ? (long)y * W + x : 0;
+        const long pix = pix_ok ? pix_off(a.ld, y, x) : 0;
         float h_r[16], z_r[16];
         if (a.bmap) {  // precomputed context term of the GRU convs (constant over the iterations of a pair)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
                 const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
-                bias_r[reg] = ok ? a.bmap[b * a.bmbs + co * HW + pix] : 0.f;
+                bias_r[reg] = ok ? a.bmap[b * a.bmbs + co * DP + pix] : 0.f;
             }
         }
         if (epi == EPI_GRU_ZR || epi == EPI_GRU_Q) {
@@ -367,11 +369,11 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
                 z_r[reg] = 0.f;
                 if (epi == EPI_GRU_Q) {
                     if (ok) {
-                        h_r[reg] = a.aux0[b * a.abs0 + co * HW + pix];
-                        z_r[reg] = a.aux1[b * a.abs1 + co * HW + pix];
+                        h_r[reg] = a.aux0[b * a.abs0 + co * DP + pix];
+                        z_r[reg] = a.aux1[b * a.abs1 + co * DP + pix];
                     }
                 } else if (ok && co >= a.hidden) {
-                    h_r[reg] = a.aux0[b * a.abs0 + (co - a.hidden) * HW + pix];
+                    h_r[reg] = a.aux0[b * a.abs0 + (co - a.hidden) * DP + pix];
                 }
             }
         }
@@ -383,29 +385,20 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
             if (co >= a.Cout) continue;
             const float v = acc[pp][reg] + bias_r[reg];
             if (epi == EPI_RELU) {
-                a.out0[b * a.obs0 + co * HW + pix] = fmaxf(v, 0.f);
+                a.out0[b * a.obs0 + co * DP + pix] = fmaxf(v, 0.f);
             } else if (epi == EPI_LINEAR) {
-                a.out0[b * a.obs0 + co * HW + pix] = v;
+                a.out0[b * a.obs0 + co * DP + pix] = v;
             } else if (epi == EPI_SCALE) {
-                a.out0[b * a.obs0 + co * HW + pix] = a.scale * v;
+                a.out0[b * a.obs0 + co * DP + pix] = a.scale * v;
             } else if (epi == EPI_GRU_ZR) {
                 const float sg = sigmoidf_(v);
-                if (co < a.hidden) a.out0[b * a.obs0 + co * HW + pix] = sg;
-                else a.out1[b * a.obs1 + (co - a.hidden) * HW + pix] = sg * h_r[reg];
-            } else if (epi == EPI_GRU_Q) {
+                if (co < a.hidden) a.out0[b * a.obs0 + co * DP + pix] = sg;
+                else a.out1[b * a.obs1 + (co - a.hidden) * DP + pix] = sg * h_r[reg];
+            } else {  // EPI_GRU_Q
                 const float q = tanhf_(v);
                 const float hn = (1.0f - z_r[reg]) * h_r[reg] + z_r[reg] * q;
-                a.out0[b * a.obs0 + co * HW + pix] = hn;
-                if (a.out1) a.out1[b * a.obs1 + co * HW + pix] = hn;
-            } else {  // EPI_ADVANCE (Cout == 1: only co == 0 reaches here)
-                float* coords = const_cast<float*>(a.aux0);
-                float* hx_flow = const_cast<float*>(a.aux1);
-                const float cnew = coords[b * a.abs0 + pix] + v;
-                const float f = a.hidden ? cnew : cnew - (float)x;  // hidden != 0: absolute coordinates (IGEV)
-                a.out0[b * a.obs0 + pix] = v;
-                coords[b * a.abs0 + pix] = cnew;
-                a.out1[b * a.obs1 + pix] = f;
-                hx_flow[b * a.abs1 + pix] = f;
+                a.out0[b * a.obs0 + co * DP + pix] = hn;
+                if (a.out1) a.out1[b * a.obs1 + co * DP + pix] = hn;
             }
         }
     }
@@ -506,7 +499,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
                 hipStream_t stream) {
     NND_REQUIRE(io.src0.C + io.src1.C == L.Cin, "conv: source channels %d+%d != Cin %d", io.src0.C, io.src1.C, L.Cin);
     NND_REQUIRE(io.src1.C == 0 || io.src0.C % L.CI_T == 0, "conv: first source (%d ch) must be a multiple of %d", io.src0.C, L.CI_T);
-    NND_REQUIRE((long)(L.Cin + 2 * L.CI_T) * H * W < (1L << 31), "conv: plane offsets exceed 32 bits");
+    NND_REQUIRE((long)(L.Cin + 2 * L.CI_T) * tiled_plane(H, W) < (1L << 31), "conv: plane offsets exceed 32 bits");
     TileCfg cfg;
     NND_REQUIRE(pick_tile(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv: no tile configuration for %dx%d Cin=%d", L.KH, L.KW, L.Cin);
     ConvArgs a;
@@ -520,6 +513,8 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
+    a.ls = make_lay(H, W, io.src_tiled);
+    a.ld = make_lay(H, W, io.dst_tiled);
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks;
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;

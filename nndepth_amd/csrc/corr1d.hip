@@ -16,6 +16,7 @@
 // This file is compiled with -ffp-contract=off so the lookup reproduces the reference's
 // mul/mul/add rounding sequence bit for bit.
 #include "common.h"
+#include "layout.h"
 
 namespace nnd {
 
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(256) corr1d_build_kernel(const float* __restri
 struct LookupArgs {
     PyrLayout L;
     int B, H, W, num_levels, radius;
+    Lay lay;  // layout of coords (in) and of the sampled features (out): NCHW for the C-ABI, tile-major in the loop
 };
 
 __global__ void __launch_bounds__(256) corr1d_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
@@ -111,7 +113,8 @@ __global__ void __launch_bounds__(256) corr1d_lookup_kernel(const float* __restr
     const int lvl = ch / ntap, k = ch - lvl * ntap;
     const int w2 = a.L.width[lvl];
     const float* row = pyr + a.L.off[lvl] + ((long)b * HW + pix) * w2;
-    float x = (float)(k - a.radius) + coords[(long)b * HW + pix] / (float)(1 << lvl);
+    const long po = pix_off(a.lay, (int)(pix / a.W), (int)(pix % a.W));
+    float x = (float)(k - a.radius) + coords[(long)b * a.lay.plane + po] / (float)(1 << lvl);
     const float wm1 = (float)(w2 - 1);
     x = x / wm1;
     x = fminf(fmaxf(x, 0.f), 1.f);
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(256) corr1d_lookup_kernel(const float* __restr
     const float f0 = floorf(x), f1 = ceilf(x);
     const float v0 = row[(int)f0], v1 = row[(int)f1];
     const float coef = f1 - x;
-    out[idx] = coef * v0 + (1.0f - coef) * v1;
+    out[((long)b * (a.num_levels * ntap) + ch) * a.lay.plane + po] = coef * v0 + (1.0f - coef) * v1;
 }
 
 // level l = avg_pool1d(level l-1, 2) (floor on odd widths) for a pyramid whose level 0 came from elsewhere
@@ -151,7 +154,8 @@ __global__ void __launch_bounds__(256) igev_lookup_kernel(const float* __restric
     const int k = ch % ntap, g = (ch / ntap) % G, v = (ch / (ntap * G)) % 2, lvl = ch / (ntap * G * 2);
     const int w2 = a.L.width[lvl];
     const float* row = (v ? geo : feat) + a.L.off[lvl] + (((long)b * G + g) * HW + pix) * w2;
-    float x = coords[(long)b * HW + pix] / (float)(1 << lvl) + (float)(k - a.radius);
+    const long po = pix_off(a.lay, (int)(pix / a.W), (int)(pix % a.W));
+    float x = coords[(long)b * a.lay.plane + po] / (float)(1 << lvl) + (float)(k - a.radius);
     const float wm1 = (float)(w2 - 1);
     x = x / wm1;
     x = fminf(fmaxf(x, 0.f), 1.f);
@@ -159,14 +163,14 @@ __global__ void __launch_bounds__(256) igev_lookup_kernel(const float* __restric
     const float f0 = floorf(x), f1 = ceilf(x);
     const float v0 = row[(int)f0], v1 = row[(int)f1];
     const float coef = f1 - x;
-    out[idx] = coef * v0 + (1.0f - coef) * v1;
+    out[((long)b * nch + ch) * a.lay.plane + po] = coef * v0 + (1.0f - coef) * v1;
 }
 
 // out[b, c, r*h + i, r*w + j] = sum_k softmax_k(mask[b, k*r*r + i*r + j, h, w]) * (r * flow)[b, c, h+ky-1, w+kx-1]
 // thread = (b, h, i, w); loops j (r consecutive outputs -> contiguous store) and c.
 template <int RATE>
 __global__ void __launch_bounds__(256) convex_upsample_kernel(const float* __restrict__ flow, const float* __restrict__ mask,
-                                                              float* __restrict__ out, int B, int C, int H, int W) {
+                                                              float* __restrict__ out, int B, int C, int H, int W, Lay lay) {
     const long total = (long)B * H * RATE * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -174,15 +178,15 @@ __global__ void __launch_bounds__(256) convex_upsample_kernel(const float* __res
     const int i = (int)((idx / W) % RATE);
     const int h = (int)((idx / ((long)W * RATE)) % H);
     const int b = (int)(idx / ((long)W * RATE * H));
-    const long HW = (long)H * W;
-    const float* mb = mask + (long)b * 9 * RATE * RATE * HW + (long)h * W + w;
+    const long HW = lay.plane;
+    const float* mb = mask + (long)b * 9 * RATE * RATE * HW + pix_off(lay, h, w);
     for (int c = 0; c < C; ++c) {
         float nb[9];
         const float* fb = flow + ((long)b * C + c) * HW;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
-            nb[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)RATE * fb[(long)yy * W + xx] : 0.f;
+            nb[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)RATE * fb[pix_off(lay, yy, xx)] : 0.f;
         }
         float res[RATE];
 #pragma unroll
@@ -212,11 +216,12 @@ __global__ void __launch_bounds__(256) convex_upsample_kernel(const float* __res
 }
 
 int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,
-                         int radius, hipStream_t stream) {
+                         int radius, hipStream_t stream, bool tiled) {
     NND_REQUIRE(num_levels >= 1 && num_levels < MAX_LEVELS, "lookup: num_levels %d out of range", num_levels);
     LookupArgs a;
     make_layout(B, H, W, num_levels + 1, &a.L, nullptr);
     a.B = B; a.H = H; a.W = W; a.num_levels = num_levels; a.radius = radius;
+    a.lay = make_lay(H, W, tiled);
     NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
     long total = (long)B * num_levels * (2 * radius + 1) * H * W;
     hipLaunchKernelGGL(corr1d_lookup_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, pyr, coords, out, a);
@@ -225,15 +230,16 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
 }
 
 int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool tiled) {
+    const Lay lay = make_lay(H, W, tiled);
     long total = (long)B * H * rate * W;
     dim3 grid((unsigned)cdiv64(total, 256)), block(256);
     if (rate == 8)
-        hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, block, 0, stream, flow, mask, out, B, C, H, W);
+        hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, block, 0, stream, flow, mask, out, B, C, H, W, lay);
     else if (rate == 4)
-        hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, block, 0, stream, flow, mask, out, B, C, H, W);
+        hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, block, 0, stream, flow, mask, out, B, C, H, W, lay);
     else if (rate == 2)
-        hipLaunchKernelGGL(convex_upsample_kernel<2>, grid, block, 0, stream, flow, mask, out, B, C, H, W);
+        hipLaunchKernelGGL(convex_upsample_kernel<2>, grid, block, 0, stream, flow, mask, out, B, C, H, W, lay);
     else {
         set_error("convex_upsample: rate %d not supported (2, 4, 8)", rate);
         return NND_ERR_UNSUPPORTED;
@@ -307,32 +313,43 @@ int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels,
     return NND_OK;
 }
 
-int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
-                    int W, int num_levels, int radius, void* stream) {
+}  // extern "C"
+
+namespace nnd {
+int igev_lookup_launch(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
+                       int W, int num_levels, int radius, hipStream_t stream, bool tiled) {
     NND_REQUIRE(feat_pyramid && geo_pyramid && coords && out, "igev_lookup: null pointer");
     NND_REQUIRE(B > 0 && G > 0 && H > 0 && W > 0 && radius >= 0 && num_levels >= 1 && num_levels < MAX_LEVELS, "igev_lookup: bad shape");
     LookupArgs a;
     make_layout(B * G, H, W, num_levels + 1, &a.L, nullptr);
     a.B = B; a.H = H; a.W = W; a.num_levels = num_levels; a.radius = radius;
+    a.lay = make_lay(H, W, tiled);
     NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "igev_lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
     long total = (long)B * num_levels * 2 * G * (2 * radius + 1) * H * W;
-    hipLaunchKernelGGL(igev_lookup_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, feat_pyramid,
+    hipLaunchKernelGGL(igev_lookup_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, feat_pyramid,
                        geo_pyramid, coords, out, a, G);
     NND_LAUNCH_CHECK();
     return NND_OK;
+}
+}  // namespace nnd
+
+extern "C" {
+int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
+                    int W, int num_levels, int radius, void* stream) {
+    return igev_lookup_launch(feat_pyramid, geo_pyramid, coords, out, B, G, H, W, num_levels, radius, (hipStream_t)stream, false);
 }
 
 int nnd_corr1d_lookup(const float* pyramid, const float* coords, float* out, int B, int H, int W, int num_levels,
                       int radius, void* stream) {
     NND_REQUIRE(pyramid && coords && out, "corr1d_lookup: null pointer");
     NND_REQUIRE(B > 0 && H > 0 && W > 0 && radius >= 0, "corr1d_lookup: bad shape");
-    return corr1d_lookup_launch(pyramid, coords, out, B, H, W, num_levels, radius, (hipStream_t)stream);
+    return corr1d_lookup_launch(pyramid, coords, out, B, H, W, num_levels, radius, (hipStream_t)stream, false);
 }
 
 int nnd_convex_upsample(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
                         void* stream) {
     NND_REQUIRE(flow && mask && out, "convex_upsample: null pointer");
     NND_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "convex_upsample: bad shape");
-    return convex_upsample_launch(flow, mask, out, B, C, H, W, rate, (hipStream_t)stream);
+    return convex_upsample_launch(flow, mask, out, B, C, H, W, rate, (hipStream_t)stream, false);
 }
 }

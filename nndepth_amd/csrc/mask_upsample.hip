@@ -13,6 +13,7 @@
 //     9 logits from LDS -> softmax -> weighted sum of the 3x3 flow neighbourhood -> R*8 contiguous floats per
 //     (tile row, sub-row) so the HBM stores are whole 256-B runs.
 #include "common.h"
+#include "layout.h"
 
 namespace nnd {
 
@@ -26,6 +27,7 @@ struct MaskUpArgs {
     const float* flow;  // (B,1,H,W)
     float* out;         // (B,1,R*H,R*W)
     int H, W, tiles_x;
+    Lay lay;  // layout of x and flow (tile-major inside the loop, NCHW through the C-ABI)
 };
 
 template <int RATE, int CIN>
@@ -62,6 +64,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     const int b = blockIdx.z;
     const int H = a.H, W = a.W;
     const long HW = (long)H * W;
+    const long XP = a.lay.plane;
 
     // ---- stage the x tile (all CIN channels) and the flow patch
     {
@@ -74,7 +77,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             const int ci = e >> 5, px = e & 31;
             const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
             const bool ok = e < CIN * 32 && y < H && x < W;
-            v[i] = src[ok ? (unsigned)(ci * (int)HW + y * W + x) : 0u];
+            v[i] = src[ok ? (unsigned)(ci * (int)XP + (int)pix_off(a.lay, y, x)) : 0u];
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -86,7 +89,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
         if (tid < 60) {
             const int pr = tid / 10, pc = tid % 10;
             const int y = ty0 + pr - 1, x = tx0 + pc - 1;
-            fp[tid] = (y >= 0 && y < H && x >= 0 && x < W) ? a.flow[b * HW + (long)y * W + x] : 0.f;
+            fp[tid] = (y >= 0 && y < H && x >= 0 && x < W) ? a.flow[b * XP + pix_off(a.lay, y, x)] : 0.f;
         }
     }
     __syncthreads();
@@ -210,12 +213,13 @@ bool mask_upsample_supported(int rate, int cin, int flow_channels) {
 }
 
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream) {
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled) {
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == 128 && L.Cout == 9 * rate * rate, "mask_upsample: layer shape");
     NND_REQUIRE(mask_upsample_supported(rate, L.Cin, 1), "mask_upsample: rate %d / Cin %d not built", rate, L.Cin);
     MaskUpArgs a;
     a.x = x; a.xbs = xbs; a.wpk = blob + L.w_off; a.bias = blob + L.b_off; a.flow = flow; a.out = out;
     a.H = H; a.W = W; a.tiles_x = cdiv(W, 8);
+    a.lay = make_lay(H, W, tiled);
     if (rate == 8 && L.Cin == 256) return launch_mu<8, 256>(a, B, stream);
     if (rate == 8 && L.Cin == 128) return launch_mu<8, 128>(a, B, stream);
     if (rate == 4 && L.Cin == 256) return launch_mu<4, 256>(a, B, stream);

@@ -13,6 +13,7 @@
 // flow branch (convf1 -> convf2) and the mask branch (mask.0 -> mask.2 -> convex upsample, which only feeds the
 // output) run on two side streams beside the critical path (see Streams / run_iteration).
 #include "common.h"
+#include "layout.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -103,7 +104,7 @@ struct Bufs {
 };
 
 static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
-    const int64_t n = (int64_t)B * H * W;
+    const int64_t n = (int64_t)B * tiled_plane(H, W);  // every workspace tensor is tile-major (layout.h)
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels;
     int64_t off = 0;
     auto take = [&](int C) {
@@ -135,17 +136,17 @@ static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
 template <int FC>
 __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ flow, long fbs, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out, long obs,
-                                                     int H, int W, int tiles_x) {
+                                                     int H, int W, int tiles_x, Lay lay) {
     __shared__ float patch[FC][14][40];
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
     const int b = blockIdx.z, co0 = blockIdx.y * 32;
-    const long HW = (long)H * W;
+    const long HW = lay.plane;
     for (int e = tid; e < FC * 14 * 38; e += 256) {
         int c = e / (14 * 38), rem = e % (14 * 38);
         int pr = rem / 38, pc = rem % 38;
         int gy = ty0 + pr - 3, gx = tx0 + pc - 3;
-        patch[c][pr][pc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? flow[b * fbs + c * HW + (long)gy * W + gx] : 0.f;
+        patch[c][pr][pc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? flow[b * fbs + c * HW + pix_off(lay, gy, gx)] : 0.f;
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
@@ -164,41 +165,61 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
 #pragma unroll
         for (int i = 0; i < FC * 49; ++i) acc = fmaf(wc[i], v[i], acc);
         acc += bias[co];
-        if (ok) out[b * obs + co * HW + (long)y * W + x] = fmaxf(acc, 0.f);
+        if (ok) out[b * obs + co * HW + pix_off(lay, y, x)] = fmaxf(acc, 0.f);
     }
 }
 
 // coords += delta; flow = coords - x  (model.py:134-135), mirrored into the GRU input buffer.
 __global__ void advance_kernel(float* __restrict__ coords, const float* __restrict__ delta, float* __restrict__ flow,
-                               float* __restrict__ hx_flow, long hx_bs, int B, int H, int W, int absolute) {
+                               float* __restrict__ hx_flow, long hx_bs, int B, int H, int W, int absolute, Lay lay) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
     const int b = (int)(idx / HW);
     const long pix = idx % HW;
     const int x = (int)(pix % W);
-    float cnew = coords[idx] + delta[idx];
+    const long o = b * lay.plane + pix_off(lay, (int)(pix / W), x);
+    float cnew = coords[o] + delta[o];
     float f = absolute ? cnew : cnew - (float)x;
-    coords[idx] = cnew;
-    flow[idx] = f;
-    hx_flow[b * hx_bs + pix] = f;
+    coords[o] = cnew;
+    flow[o] = f;
+    hx_flow[b * hx_bs + (o - b * lay.plane)] = f;
 }
 
 // coords = x (+ disp_init); flow = coords - x
 // absolute != 0 (IGEV, Q5): the update block and the upsample receive the coordinate itself, not coords - x
 __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict__ flow, float* __restrict__ hx_flow,
-                                   long hx_bs, const float* __restrict__ disp_init, int B, int H, int W, int absolute) {
+                                   long hx_bs, const float* __restrict__ disp_init, int B, int H, int W, int absolute, Lay lay) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
     const int b = (int)(idx / HW);
     const long pix = idx % HW;
     const int x = (int)(pix % W);
-    float c = (float)x + (disp_init ? disp_init[idx] : 0.f);
+    const long po = pix_off(lay, (int)(pix / W), x);
+    float c = (float)x + (disp_init ? disp_init[idx] : 0.f);  // disp_init is a C-ABI tensor: NCHW
     float f = absolute ? c : c - (float)x;
-    coords[idx] = c;
-    flow[idx] = f;
-    hx_flow[b * hx_bs + pix] = f;
+    coords[b * lay.plane + po] = c;
+    flow[b * lay.plane + po] = f;
+    hx_flow[b * hx_bs + po] = f;
+}
+
+// NCHW (C-ABI) <-> tile-major (workspace) copies of a C-channel tensor; dst/src batch strides in floats
+__global__ void to_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, long dbs, int B, int C, int H, int W, Lay lay) {
+    const long HW = (long)H * W;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C * HW) return;
+    const long pix = idx % HW;
+    const int c = (int)((idx / HW) % C), b = (int)(idx / (HW * C));
+    dst[b * dbs + c * lay.plane + pix_off(lay, (int)(pix / W), (int)(pix % W))] = src[idx];
+}
+__global__ void from_tiled_kernel(const float* __restrict__ src, long sbs, float* __restrict__ dst, int B, int C, int H, int W, Lay lay) {
+    const long HW = (long)H * W;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C * HW) return;
+    const long pix = idx % HW;
+    const int c = (int)((idx / HW) % C), b = (int)(idx / (HW * C));
+    dst[idx] = src[b * sbs + c * lay.plane + pix_off(lay, (int)(pix / W), (int)(pix % W))];
 }
 
 // flow_head.conv2: 3x3, hid -> FC (1 or 2) outputs.  One output channel wastes 31/32 of an MFMA tile, so this is a
@@ -211,19 +232,19 @@ __global__ void __launch_bounds__(256) flow_head2_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ delta,
                                                          float* __restrict__ coords, float* __restrict__ flow,
                                                          float* __restrict__ hx_flow, long hx_bs, int H, int W, int tiles_x,
-                                                         int advance, int absolute) {
+                                                         int advance, int absolute, Lay lay) {
     extern __shared__ float sm[];
     float* patch = sm;                 // [hid][60]
     float* wl = sm + hid * 60;         // [FC][hid][9]
     float* part = wl + FC * hid * 9;   // [8][FC][32]
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
-    const long HW = (long)H * W;
+    const long HW = lay.plane;
     const float* src = x + b * xbs;
     for (int e = tid; e < hid * 60; e += 256) {
         const int ci = e / 60, pos = e % 60;
         const int gy = ty0 + pos / 10 - 1, gx = tx0 + pos % 10 - 1;
-        patch[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[ci * HW + (long)gy * W + gx] : 0.f;
+        patch[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[ci * HW + pix_off(lay, gy, gx)] : 0.f;
     }
     for (int e = tid; e < FC * hid * 9; e += 256) wl[e] = w[e];
     __syncthreads();
@@ -253,7 +274,7 @@ __global__ void __launch_bounds__(256) flow_head2_kernel(const float* __restrict
         sum += bias[f];
         const int y = ty0 + (p2 >> 3), xx = tx0 + (p2 & 7);
         if (y < H && xx < W) {
-            const long pix = (long)y * W + xx;
+            const long pix = pix_off(lay, y, xx);
             delta[(b * FC + f) * HW + pix] = sum;
             if (advance) {  // FC == 1 on this path
                 const float cnew = coords[b * HW + pix] + sum;
@@ -345,6 +366,7 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.scale = 0.25f;
             break;
     }
+    io.src_tiled = io.dst_tiled = true;  // workspace tensors are tile-major (layout.h)
     return io;
 }
 
@@ -372,7 +394,7 @@ static int debug_sync(const char* what, hipStream_t s) {
 
 static int run_conv(const Plan& p, const float* blob, const Bufs& w, int id, Act corr, float* mask_dst, float* delta_dst,
                     int B, int H, int W, hipStream_t s, IoOpt opt = IoOpt()) {
-    ConvIO io = conv_io(p, w, id, corr, (int64_t)H * W, mask_dst, delta_dst, opt);
+    ConvIO io = conv_io(p, w, id, corr, tiled_plane(H, W), mask_dst, delta_dst, opt);
     int rc = launch_conv(p.L[id], blob, io, conv_epi(id, opt), B, H, W, s);
     if (rc != NND_OK) return rc;
     return debug_sync(kConvNames[id], s);
@@ -382,11 +404,12 @@ static int run_convf1(const Plan& p, const float* blob, const float* flow, int64
                       hipStream_t s) {
     const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8);
     dim3 grid(tiles_x * tiles_y, 4, B), block(256);
-    const int64_t n = (int64_t)H * W;
+    const Lay lay = make_lay(H, W, true);
+    const int64_t n = lay.plane;
     if (p.d.flow_channels == 1)
-        hipLaunchKernelGGL(convf1_kernel<1>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x);
+        hipLaunchKernelGGL(convf1_kernel<1>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x, lay);
     else
-        hipLaunchKernelGGL(convf1_kernel<2>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x);
+        hipLaunchKernelGGL(convf1_kernel<2>, grid, block, 0, s, flow, (long)fbs, blob + p.f1_w, blob + p.f1_b, out, (long)(128 * n), H, W, tiles_x, lay);
     NND_LAUNCH_CHECK();
     return debug_sync("encoder.convf1", s);
 }
@@ -394,7 +417,8 @@ static int run_convf1(const Plan& p, const float* blob, const float* flow, int64
 static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta_dst, bool advance, bool absolute, int B, int H,
                    int W, hipStream_t s) {
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels, hxC = 2 * hid + ctx;
-    const int64_t n = (int64_t)H * W;
+    const Lay lay = make_lay(H, W, true);
+    const int64_t n = lay.plane;
     const int tiles_x = cdiv(W, 8);
     dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(256);
     const size_t lds = (size_t)(hid * 60 + fc * hid * 9 + 8 * fc * 32) * sizeof(float);
@@ -403,10 +427,10 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     float* hx_flow = w.hx + (hxC - 1) * n;
     if (fc == 1)
         hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance ? 1 : 0, absolute ? 1 : 0);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance ? 1 : 0, absolute ? 1 : 0, lay);
     else
         hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, 0, 0);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, 0, 0, lay);
     NND_LAUNCH_CHECK();
     return debug_sync("flow_head.conv2", s);
 }
@@ -451,7 +475,7 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
     } while (0)
     NND_TRY(run_conv(p, blob, w, C_C1, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_C2, corr, nullptr, nullptr, B, H, W, s));
-    NND_TRY(run_convf1(p, blob, flow, (int64_t)p.d.flow_channels * H * W, w.f1, B, H, W, s));
+    NND_TRY(run_convf1(p, blob, flow, (int64_t)p.d.flow_channels * tiled_plane(H, W), w.f1, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_F2, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_CV, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_ZR1, corr, nullptr, nullptr, B, H, W, s));
@@ -466,6 +490,19 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
         NND_TRY(run_conv(p, blob, w, C_M0, corr, nullptr, nullptr, B, H, W, s));
         NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
     }
+    return NND_OK;
+}
+
+static int to_tiled(const float* src, float* dst, int64_t dbs, int B, int C, int H, int W, hipStream_t s) {
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, src, dst, (long)dbs, B, C, H, W, make_lay(H, W, true));
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+static int from_tiled(const float* src, int64_t sbs, float* dst, int B, int C, int H, int W, hipStream_t s) {
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(from_tiled_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, src, (long)sbs, dst, B, C, H, W, make_lay(H, W, true));
+    NND_LAUNCH_CHECK();
     return NND_OK;
 }
 
@@ -579,13 +616,18 @@ int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* pac
     Bufs w;
     carve(p, B, H, W, workspace, &w);
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels, hxC = 2 * hid + ctx;
-    const int64_t n = (int64_t)H * W;
-    NND_TRY(copy_slice(w.hx, hxC * n, net, hid * n, hid * n, B, s));
-    NND_TRY(copy_slice(w.hx + hid * n, hxC * n, inp, ctx * n, ctx * n, B, s));
-    NND_TRY(copy_slice(w.hx + (hxC - fc) * n, hxC * n, flow, fc * n, fc * n, B, s));
-    Act c = act(const_cast<float*>(corr), p.d.cor_planes * n, p.d.cor_planes);
-    NND_TRY(run_update(p, packed, w, c, flow, mask_out, delta_out, B, H, W, s));
-    NND_TRY(copy_slice(net_out, hid * n, w.hx, hxC * n, hid * n, B, s));
+    const int64_t n = tiled_plane(H, W);
+    // C-ABI tensors are NCHW, the workspace is tile-major: convert on the way in and out
+    NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s));
+    NND_TRY(to_tiled(inp, w.hx + hid * n, hxC * n, B, ctx, H, W, s));
+    NND_TRY(to_tiled(flow, w.hx + (hxC - fc) * n, hxC * n, B, fc, H, W, s));
+    NND_TRY(to_tiled(flow, w.flow, fc * n, B, fc, H, W, s));
+    NND_TRY(to_tiled(corr, w.corr, p.d.cor_planes * n, B, p.d.cor_planes, H, W, s));
+    Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
+    NND_TRY(run_update(p, packed, w, c, w.flow, mask_out ? w.mask : nullptr, w.delta, B, H, W, s));
+    NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
+    NND_TRY(from_tiled(w.delta, fc * n, delta_out, B, fc, H, W, s));
+    if (mask_out) NND_TRY(from_tiled(w.mask, p.d.mask_channels * n, mask_out, B, p.d.mask_channels, H, W, s));
     return NND_OK;
 }
 
@@ -610,18 +652,19 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     Bufs w;
     carve(p, B, H, W, workspace, &w);
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, hxC = 2 * hid + ctx;
-    const int64_t n = (int64_t)H * W;
-    NND_TRY(copy_slice(w.hx, hxC * n, net, hid * n, hid * n, B, s));
-    NND_TRY(copy_slice(w.hx + hid * n, hxC * n, inp, ctx * n, ctx * n, B, s));
+    const Lay lay = make_lay(H, W, true);
+    const int64_t n = lay.plane;  // channel stride of every (tile-major) workspace tensor
+    NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s));
+    NND_TRY(to_tiled(inp, w.hx + hid * n, hxC * n, B, ctx, H, W, s));
     float* hx_flow = w.hx + (hxC - 1) * n;
-    const unsigned eg = (unsigned)cdiv64((int64_t)B * n, 256);
+    const unsigned eg = (unsigned)cdiv64((int64_t)B * H * W, 256);
     hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H, W,
-                       igev ? 1 : 0);
+                       igev ? 1 : 0, lay);
     NND_LAUNCH_CHECK();
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
     auto lookup = [&](hipStream_t st_) -> int {
-        if (igev) return nnd_igev_lookup(pyramid, geo_pyramid, w.coords, w.corr, B, groups, H, W, num_levels, radius, st_);
-        return corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, st_);
+        if (igev) return igev_lookup_launch(pyramid, geo_pyramid, w.coords, w.corr, B, groups, H, W, num_levels, radius, st_, true);
+        return corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, st_, true);
     };
     // per-pair context terms of the GRU convs (inp is constant over the iterations)
     for (int id : {(int)C_ZR1C, (int)C_Q1C, (int)C_ZR2C, (int)C_Q2C})
@@ -633,9 +676,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(lookup(s));
             NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
             hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W,
-                               igev ? 1 : 0);
+                               igev ? 1 : 0, lay);
             NND_LAUNCH_CHECK();
-            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s));
+            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s, true));
         }
     } else {
         // Per-iteration DAG over three streams (M = caller's stream carries the recurrence):
@@ -680,16 +723,16 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
             if (fused_up)  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
                 NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow,
-                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, st->b));
+                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, st->b, true));
             else
-                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, st->b));
+                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, st->b, true));
             NND_HIP_CHECK(hipEventRecord(st->up, st->b));
         }
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));   // join B
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));   // join A (already consumed, keeps the contract simple)
     }
-    if (low_out) NND_TRY(copy_slice(low_out, n, w.flow, n, n, B, s));
-    if (net_out) NND_TRY(copy_slice(net_out, hid * n, w.hx, hxC * n, hid * n, B, s));
+    if (low_out) NND_TRY(from_tiled(w.flow, n, low_out, B, 1, H, W, s));
+    if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
     return NND_OK;
 }
 
@@ -833,7 +876,7 @@ int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const flo
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed_dev && x && flow && out && B > 0 && H > 0 && W > 0, "mask_upsample_forward: bad argument");
     NND_REQUIRE(mask_upsample_supported(rate, Cin, 1), "mask_upsample_forward: rate %d / Cin %d not built", rate, Cin);
-    return mask_upsample_launch(L, packed_dev, x, (int64_t)Cin * H * W, flow, out, B, H, W, rate, (hipStream_t)stream);
+    return mask_upsample_launch(L, packed_dev, x, (int64_t)Cin * H * W, flow, out, B, H, W, rate, (hipStream_t)stream, false);
 }
 
 int nnd_num_convs(const nnd_update_block_desc* desc) {
@@ -858,7 +901,7 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, flo
     hipStream_t s = (hipStream_t)stream;
     Bufs w;
     carve(p, B, H, W, workspace, &w);
-    const int64_t n = (int64_t)H * W;
+    const int64_t n = tiled_plane(H, W);
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
     hipEvent_t e0, e1;
     NND_HIP_CHECK(hipEventCreate(&e0));
