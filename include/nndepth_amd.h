@@ -79,6 +79,26 @@ int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels,
 int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out,
                     int B, int G, int H, int W, int num_levels, int radius, void* stream);
 
+/* ------------------------------------------------- CREStereo adaptive group correlation (AGCL)
+ * Replaces AGCL.corr_iter / get_correlation / corr_att_offset and bilinear_sampler / bilinear_grid_sample
+ *   nndepth/models/cre_stereo/cost_volume.py:28-79, :81-154;  nndepth/models/cre_stereo/utils.py:5-20,34-107
+ * Channels are split into 4 groups of C/4; the 9 search positions are a 1x9 window (small_patch = 0) or a 3x3
+ * window (small_patch = 1, dy outer / dx inner); out (N,36,H,W), channel = g*9 + k.
+ * nnd_bilinear_sample : img (N,C,H,W), coords (N,Hg,Wg,2) = (x,y) in pixels -> out (N,C,Hg,Wg); taps outside the
+ *                       image read zero (grid_sample zeros/align_corners=True semantics incl. the reference's
+ *                       pixel -> [-1,1] -> pixel round trip).
+ * nnd_agcl_corr_iter  : flow (N,2,H,W); the right features are warped by grid+flow into `warped` (caller-owned
+ *                       scratch, N*C*H*W floats), then correlated over the window of the replicate-padded warped map.
+ * nnd_agcl_corr_offset: each search position samples fmap2 at grid + flow + window + extra_offset, extra_offset
+ *                       (N,18,H,W) with channel 2k = x, 2k+1 = y of position k.  The optional cross attention of the
+ *                       reference (att != None) is applied by the caller to fmap1/fmap2 beforehand.             */
+int nnd_bilinear_sample(const float* img, const float* coords, float* out, int N, int C, int H, int W, int Hg, int Wg,
+                        void* stream);
+int nnd_agcl_corr_iter(const float* fmap1, const float* fmap2, const float* flow, float* warped, float* out,
+                       int N, int C, int H, int W, int small_patch, void* stream);
+int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* flow, const float* extra_offset, float* out,
+                         int N, int C, int H, int W, int small_patch, void* stream);
+
 /* ----------------------------------------------------------------------- convex upsample
  * Replaces RAFTStereo.convex_upsample  nndepth/models/raft_stereo/model.py:93-105
  * (IGEV copy igev_stereo/model.py:103-115; 2-channel CRE copy cre_stereo/model.py:110-122)

@@ -33,6 +33,9 @@ SIGNATURES = {
     "nnd_pyramid_from_level0": (_I, [_P, _I, _I, _I, _I, _P]),
     "nnd_igev_lookup": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_convex_upsample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_bilinear_sample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_agcl_corr_iter": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_agcl_corr_offset": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_update_block_num_tensors": (_I, [C.POINTER(UpdateBlockDesc)]),
     "nnd_update_block_packed_floats": (C.c_int64, [C.POINTER(UpdateBlockDesc)]),
     "nnd_update_block_pack": (_I, [C.POINTER(UpdateBlockDesc), C.POINTER(_P), _P]),

@@ -73,3 +73,33 @@ class GeometryAwareCostVolume:
         return ops.igev_lookup(self._feat, self._geo, coords.float(), self.num_groups, self.num_levels, self.radius)
 
     forward = __call__
+
+
+class AGCL:
+    """Drop-in for the reference's adaptive group correlation layer
+    (nndepth/models/cre_stereo/cost_volume.py:7-154): same constructor `(fmap1, fmap2, att=None)` and call
+    `(flow, extra_offset, small_patch=False, iter_mode=False) -> (N,36,H,W)`.  The warp / window correlation /
+    offset sampling run in HIP (csrc/agcl.hip); `att` — the LoFTR cross attention of the 1/32 stage, an arbitrary
+    callable on (N, H*W, C) tokens — is called as given, exactly where the reference calls it."""
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, att=None):
+        self.fmap1 = fmap1.float().contiguous()
+        self.fmap2 = fmap2.float().contiguous()
+        self.att = att
+        self._scratch = None  # warped right features of iter mode, reused over the iterations
+
+    def __call__(self, flow: torch.Tensor, extra_offset: torch.Tensor, small_patch: bool = False,
+                 iter_mode: bool = False) -> torch.Tensor:
+        if iter_mode:
+            if self._scratch is None:
+                self._scratch = torch.empty_like(self.fmap2)
+            return ops.agcl_corr_iter(self.fmap1, self.fmap2, flow.float(), small_patch, self._scratch)
+        f1, f2 = self.fmap1, self.fmap2
+        if self.att is not None:
+            N, C, H, W = f1.shape
+            a = f1.permute(0, 2, 3, 1).reshape(N, H * W, C)
+            b = f2.permute(0, 2, 3, 1).reshape(N, H * W, C)
+            a, b = self.att(a, b)
+            f1 = a.reshape(N, H, W, C).permute(0, 3, 1, 2)
+            f2 = b.reshape(N, H, W, C).permute(0, 3, 1, 2)
+        return ops.agcl_corr_offset(f1, f2, flow.float(), extra_offset.float(), small_patch)

@@ -297,3 +297,51 @@ def igev_lookup(feat_pyr: torch.Tensor, geo_pyr: torch.Tensor, coords: torch.Ten
         check(lib.nnd_igev_lookup(_p(feat_pyr), _p(geo_pyr), _p(coords), _p(out), B, num_groups, H, W, num_levels,
                                   radius, _stream(d)), "igev_lookup")
     return out
+
+
+# ------------------------------------------------------------------ CREStereo AGCL (include/nndepth_amd.h)
+def bilinear_sample(img: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """img (N,C,H,W), coords (N,Hg,Wg,2) pixel (x,y) -> (N,C,Hg,Wg); zero outside (cre_stereo/utils.py:5-20)."""
+    d = _dev(img, coords)
+    img, coords = img.contiguous(), coords.contiguous()
+    N, C, H, W = img.shape
+    if coords.dim() != 4 or coords.shape[0] != N or coords.shape[3] != 2:
+        raise NndError(f"bilinear_sample: coords {tuple(coords.shape)} must be (N={N}, Hg, Wg, 2)")
+    Hg, Wg = coords.shape[1], coords.shape[2]
+    out = torch.empty((N, C, Hg, Wg), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_bilinear_sample(_p(img), _p(coords), _p(out), N, C, H, W, Hg, Wg, _stream(d)), "bilinear_sample")
+    return out
+
+
+def agcl_corr_iter(fmap1: torch.Tensor, fmap2: torch.Tensor, flow: torch.Tensor, small_patch: bool,
+                   scratch: torch.Tensor = None) -> torch.Tensor:
+    """cre_stereo/cost_volume.py:51-79.  scratch: optional (N,C,H,W) buffer for the warped right features."""
+    d = _dev(fmap1, fmap2, flow)
+    fmap1, fmap2, flow = fmap1.contiguous(), fmap2.contiguous(), flow.contiguous()
+    N, C, H, W = fmap1.shape
+    if fmap2.shape != fmap1.shape or tuple(flow.shape) != (N, 2, H, W):
+        raise NndError(f"agcl_corr_iter: shapes {tuple(fmap1.shape)}, {tuple(fmap2.shape)}, flow {tuple(flow.shape)}")
+    if scratch is None or scratch.numel() < fmap2.numel():
+        scratch = torch.empty_like(fmap2)
+    out = torch.empty((N, 36, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_agcl_corr_iter(_p(fmap1), _p(fmap2), _p(flow), _p(scratch), _p(out), N, C, H, W,
+                                     int(bool(small_patch)), _stream(d)), "agcl_corr_iter")
+    return out
+
+
+def agcl_corr_offset(fmap1: torch.Tensor, fmap2: torch.Tensor, flow: torch.Tensor, extra_offset: torch.Tensor,
+                     small_patch: bool) -> torch.Tensor:
+    """cre_stereo/cost_volume.py:81-154 after the optional attention."""
+    d = _dev(fmap1, fmap2, flow, extra_offset)
+    fmap1, fmap2, flow, extra_offset = (t.contiguous() for t in (fmap1, fmap2, flow, extra_offset))
+    N, C, H, W = fmap1.shape
+    if fmap2.shape != fmap1.shape or tuple(flow.shape) != (N, 2, H, W) or extra_offset.numel() != N * 18 * H * W:
+        raise NndError(f"agcl_corr_offset: shapes {tuple(fmap1.shape)}, {tuple(fmap2.shape)}, flow {tuple(flow.shape)}, "
+                       f"extra_offset {tuple(extra_offset.shape)}")
+    out = torch.empty((N, 36, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_agcl_corr_offset(_p(fmap1), _p(fmap2), _p(flow), _p(extra_offset), _p(out), N, C, H, W,
+                                       int(bool(small_patch)), _stream(d)), "agcl_corr_offset")
+    return out

@@ -31,6 +31,14 @@ def raft_sd():
 
 
 @pytest.fixture(scope="session")
+def cre_sd():
+    """Deterministic CREStereoBase weights (the ones tests/golden/cre_*.npz were made with)."""
+    from nndepth_amd import weightgen
+    from oracle import cre_ref as C
+    return weightgen.fill_state_dict(C.cre_stereo_spec())
+
+
+@pytest.fixture(scope="session")
 def tartanair_frames():
     from PIL import Image
     frames = []

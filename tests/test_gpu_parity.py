@@ -380,3 +380,79 @@ def test_igev_refine_loop_vs_oracle(R):
     for i in range(iters):
         err = (up[i].cpu() - exp[i]).abs().max().item()
         assert err <= 2e-4 * max(1.0, exp[i].abs().max().item() / 40), f"iter {i}: {err}"
+
+
+# ------------------------------------------------------------ CREStereo AGCL + sampler (a17-a19)
+@pytest.fixture(scope="module")
+def CR():
+    from oracle import cre_ref
+    return cre_ref
+
+
+@pytest.mark.parametrize("name", ["s_small", "s_wide"])
+def test_cre_bilinear_sample_golden(ops, gold, name):
+    """Same op order as the reference (round trip through [-1,1], 4 zero-bordered taps): bit-exact."""
+    g = gold("cre_sampler.npz")
+    out = ops.bilinear_sample(t(g[name + "_img"]).to(DEV), t(g[name + "_coords"]).to(DEV))
+    assert np.array_equal(out.cpu().numpy(), g[name + "_out"])
+
+
+@pytest.mark.parametrize("name", ["c32", "c256", "c64_big"])
+@pytest.mark.parametrize("sp", [0, 1])
+def test_cre_agcl_golden(ops, gold, name, sp):
+    """Both AGCL modes and both window shapes against the imported reference; the only difference is the order of
+    the channel sum inside the mean (<= 64 terms of magnitude <= 1): <= 2e-7."""
+    g = gold("cre_agcl.npz")
+    f1, f2, flow, off = (t(g[f"{name}_{k}"]).to(DEV) for k in ("f1", "f2", "flow", "off"))
+    it = ops.agcl_corr_iter(f1, f2, flow, bool(sp))
+    assert np.abs(it.cpu().numpy() - g[f"{name}_iter_sp{sp}"]).max() <= 2e-7
+    of = ops.agcl_corr_offset(f1, f2, flow, off, bool(sp))
+    assert np.abs(of.cpu().numpy() - g[f"{name}_off_sp{sp}"]).max() <= 2e-7
+
+
+def test_cre_agcl_class_fullsize_vs_oracle(CR):
+    """Drop-in AGCL class at the 1080x1920 config's 1/16 scale (67x120, C=256) with an attention callable run by
+    PyTorch, and at 1/8 scale in iter mode, against the oracle on the same seeded inputs."""
+    from nndepth_amd.cost_volume import AGCL
+    torch.manual_seed(5)
+    N, C, H, W = 1, 256, 67, 120
+    f1, f2 = torch.randn(N, C, H, W), torch.randn(N, C, H, W)
+    flow = torch.randn(N, 2, H, W) * 6
+    off = torch.rand(N, 18, H, W) * 2 - 1
+    lin = torch.nn.Linear(C, C, bias=False)
+
+    def att(a, b):
+        with torch.no_grad():
+            return a + 0.1 * lin.to(a.device)(b), b + 0.1 * lin.to(a.device)(a)
+
+    for sp in (False, True):
+        exp = CR.agcl_corr_att_offset(f1, f2, flow, off, sp, att=att)
+        got = AGCL(f1.to(DEV), f2.to(DEV), att=att)(flow.to(DEV), off.to(DEV), small_patch=sp)
+        assert (got.cpu() - exp).abs().max() <= 2e-5
+        exp = CR.agcl_corr_iter(f1, f2, flow, sp)
+        got = AGCL(f1.to(DEV), f2.to(DEV))(flow.to(DEV), None, small_patch=sp, iter_mode=True)
+        assert (got.cpu() - exp).abs().max() <= 2e-6
+
+
+def test_cre_agcl_properties():
+    """Size-independent properties: zero flow + zero offsets at the window centre = plain per-group channel mean of
+    f1*f2; linear in f1; samples far outside the image contribute exactly zero."""
+    from nndepth_amd import ops
+    torch.manual_seed(6)
+    N, C, H, W = 2, 64, 33, 60
+    f1, f2 = torch.randn(N, C, H, W, device=DEV), torch.randn(N, C, H, W, device=DEV)
+    z2, z18 = torch.zeros(N, 2, H, W, device=DEV), torch.zeros(N, 18, H, W, device=DEV)
+    centre = (f1 * f2).view(N, 4, C // 4, H, W).mean(2)
+    for sp, k in ((False, 4), (True, 4)):
+        a = ops.agcl_corr_offset(f1, f2, z2, z18, sp).view(N, 4, 9, H, W)[:, :, k]
+        b = ops.agcl_corr_iter(f1, f2, z2, sp).view(N, 4, 9, H, W)[:, :, k]
+        # the reference's pixel -> [-1,1] -> pixel round trip moves integer coordinates by an ulp: 1e-5, not exact
+        assert (a - centre).abs().max() <= 1e-5 and (b - centre).abs().max() <= 1e-5
+    far = torch.full((N, 2, H, W), 1e4, device=DEV)
+    assert ops.agcl_corr_offset(f1, f2, far, z18, False).abs().max() == 0
+    assert ops.agcl_corr_iter(f1, f2, far, True).abs().max() == 0
+    flow = torch.randn(N, 2, H, W, device=DEV) * 3
+    x = ops.agcl_corr_iter(2 * f1, f2, flow, False)
+    assert (x - 2 * ops.agcl_corr_iter(f1, f2, flow, False)).abs().max() == 0  # scaling by 2 is exact
+    with pytest.raises(Exception):
+        ops.agcl_corr_iter(f1[:, :62], f2[:, :62], flow, False)  # 62 channels: not 4 groups
