@@ -1,0 +1,176 @@
+"""CREStereo with the MI355X-native hot path.
+
+`CREStereoBase` keeps the reference's constructor kwargs, `state_dict()` keys (same registration order) and
+`forward(frame1, frame2, flow_init=None) -> List[{"up_disp": (N,2,H,W)}]` of
+nndepth/models/cre_stereo/model.py:17-288.  Inside `forward()`:
+
+    encoder (instance norm), avg-pools, offset convs, sine position encoding, LoFTR self/cross attention
+                              PyTorch-ROCm (adjacent rows)
+    AGCL (warp + window correlation, offset sampling)     HIP  csrc/agcl.hip          model.py:204-206,229,252,277
+    update block (2-channel flow)                         HIP  csrc/update_block.hip  model.py:231,254,279
+    convex upsample (2-channel)                           HIP  csrc/corr1d.hip        model.py:234,257,282
+
+The three stages of the cascade (1/32, 1/16 and 1/8 of the image for fnet_ds = 8) run `iters//2`, `iters//2` and
+`iters` update iterations; even iterations search a 1x9 window, odd ones a 3x3 window.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .blocks import BasicUpdateBlock
+from .cost_volume import AGCL
+from .encoder import BasicEncoder
+from .raft_stereo import load_weights
+from .upsample import convex_upsample
+
+
+# ------------------------------------------------------------------ adjacent PyTorch pieces (not the replaced path)
+class LoFTREncoderLayer(nn.Module):
+    """One LoFTR layer with linear attention (reference nndepth/blocks/transformer.py:8-66,
+    nndepth/blocks/attn_block.py:16-58); parameter names match the reference."""
+
+    def __init__(self, d_model: int, nhead: int):
+        super().__init__()
+        self.dim, self.nhead = d_model // nhead, nhead
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(2 * d_model, 2 * d_model, bias=False), nn.ReLU(),
+                                 nn.Linear(2 * d_model, d_model, bias=False))
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, x: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+        n = x.size(0)
+        q = F.elu(self.q_proj(x).view(n, -1, self.nhead, self.dim)) + 1
+        k = F.elu(self.k_proj(source).view(n, -1, self.nhead, self.dim)) + 1
+        v = self.v_proj(source).view(n, -1, self.nhead, self.dim)
+        s = v.size(1)
+        kv = torch.einsum("nshd,nshv->nhdv", k, v / s)
+        z = 1 / (torch.einsum("nlhd,nhd->nlh", q, k.sum(dim=1)) + 1e-6)
+        msg = (torch.einsum("nlhd,nhdv,nlh->nlhv", q, kv, z) * s).reshape(n, -1, self.nhead * self.dim)
+        msg = self.norm1(self.merge(msg))
+        msg = self.norm2(self.mlp(torch.cat([x, msg], dim=2)))
+        return x + msg
+
+
+class LocalFeatureTransformer(nn.Module):
+    def __init__(self, d_model: int, nhead: int, layer_names, attention: str = "linear"):
+        super().__init__()
+        if attention != "linear":
+            raise ValueError("only the linear attention of CREStereo is provided")
+        self.d_model, self.layer_names = d_model, list(layer_names)
+        self.layers = nn.ModuleList([LoFTREncoderLayer(d_model, nhead) for _ in self.layer_names])
+
+    def forward(self, feat0: torch.Tensor, feat1: torch.Tensor):
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == "self":
+                feat0, feat1 = layer(feat0, feat0), layer(feat1, feat1)
+            elif name == "cross":
+                feat0 = layer(feat0, feat1)
+                feat1 = layer(feat1, feat0)  # sees the updated feat0, like the reference
+            else:
+                raise KeyError(name)
+        return feat0, feat1
+
+
+def position_encoding_sine(d_model: int, h: int, w: int, device) -> torch.Tensor:
+    """(1, d_model, h, w) table of nndepth/blocks/pos_enc.py:22-42 incl. its `/ d_model // 2` precedence quirk."""
+    y = torch.ones(h, w).cumsum(0).unsqueeze(0)
+    x = torch.ones(h, w).cumsum(1).unsqueeze(0)
+    div = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / d_model // 2))[:, None, None]
+    pe = torch.zeros(d_model, h, w)
+    pe[0::4], pe[1::4], pe[2::4], pe[3::4] = torch.sin(x * div), torch.cos(x * div), torch.sin(y * div), torch.cos(y * div)
+    return pe[None].to(device)
+
+
+# ------------------------------------------------------------------ the model
+class CREStereoBase(nn.Module):
+    def __init__(self, fnet_cls: str = "basic_encoder", update_cls: str = "basic_update_block", iters: int = 12,
+                 max_disp: int = 192, num_fnet_channels: int = 256, hidden_dim: int = 128, context_dim: int = 128,
+                 search_num: int = 9, mixed_precision: bool = False, test_mode: bool = False, tracing: bool = False,
+                 include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True, **kwargs):
+        super().__init__()
+        if fnet_cls != "basic_encoder" or update_cls != "basic_update_block":
+            raise ValueError("CREStereoBase: only basic_encoder / basic_update_block exist (as in the reference)")
+        if context_dim != hidden_dim:
+            raise ValueError("Context dim must be equal to hidden_dim in this model")
+        if search_num != 9:
+            raise ValueError("AGCL searches 9 positions")
+        self.max_flow, self.mixed_precision, self.test_mode, self.iters = max_disp, mixed_precision, test_mode, iters
+        self.hidden_dim, self.context_dim, self.search_num = hidden_dim, context_dim, search_num
+        self.tracing, self.include_preprocessing = tracing, include_preprocessing
+        self.fnet = BasicEncoder(output_dim=num_fnet_channels, norm_fn="instance", dropout=0)
+        self.fnet_ds = 8
+        self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=4 * 9, flow_channel=2,
+                                             context_dim=context_dim, spatial_scale=self.fnet_ds)
+        self.self_att_fn = LocalFeatureTransformer(num_fnet_channels, 8, ["self"], "linear")
+        self.cross_att_fn = LocalFeatureTransformer(num_fnet_channels, 8, ["cross"], "linear")
+        self.conv_offset_16 = nn.Conv2d(num_fnet_channels, 2 * search_num, 3, padding=1)
+        self.conv_offset_8 = nn.Conv2d(num_fnet_channels, 2 * search_num, 3, padding=1)
+        self.range_16 = self.range_8 = 1
+        self.corr_cls = AGCL  # seam: same call shape as the reference's AGCL
+        self.weights, self.strict_load = weights, strict_load
+        if weights is not None:
+            load_weights(self, weights, strict_load)
+
+    def convex_upsample(self, flow, mask, rate=4):
+        return convex_upsample(flow, mask, rate)
+
+    def _stage(self, corr_fn, net, inp, flow, offset, n_iters: int, iter_mode: bool, outs: List[Dict[str, torch.Tensor]]):
+        up = None
+        for itr in range(n_iters):
+            corr = corr_fn(flow, offset, small_patch=(itr % 2 == 1), iter_mode=iter_mode)
+            net, mask, delta = self.update_block(net, inp, corr, flow)
+            flow = flow + delta
+            up = self.convex_upsample(flow, mask, rate=self.fnet_ds)
+            outs.append({"up_disp": up})
+        return net, flow, up
+
+    @torch.no_grad()
+    def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, flow_init: Optional[torch.Tensor] = None,
+                upsample: bool = True, test_mode: bool = False, **kwargs):
+        frame1, frame2 = frame1.contiguous(), frame2.contiguous()
+        hd, ds = self.hidden_dim, self.fnet_ds
+        fmap1, fmap2 = self.fnet([frame1, frame2])
+        fmap1, fmap2 = fmap1.float(), fmap2.float()
+        net, inp = torch.split(fmap1, [hd, hd], dim=1)
+        net, inp = torch.tanh(net), F.relu(inp)
+        outs: List[Dict[str, torch.Tensor]] = []
+        if flow_init is not None:
+            scale = fmap1.shape[2] / flow_init.shape[2]
+            flow = -scale * F.interpolate(flow_init, size=fmap1.shape[2:], mode="bilinear", align_corners=True)
+        else:
+            # 1/(4*ds): attention-refined features, learned offsets, cross attention inside every AGCL call
+            f1_16, f2_16 = F.avg_pool2d(fmap1, 4, stride=4), F.avg_pool2d(fmap2, 4, stride=4)
+            off16 = self.range_16 * (torch.sigmoid(self.conv_offset_16(f1_16)) - 0.5) * 2.0
+            net16, inp16 = F.avg_pool2d(net, 4, stride=4), F.avg_pool2d(inp, 4, stride=4)
+            n, c, h16, w16 = f1_16.shape
+            pe = position_encoding_sine(c, frame1.shape[2] // (ds * 4), frame1.shape[3] // (ds * 4), f1_16.device)
+            pe = pe[:, :, :h16, :w16]
+            t1 = (f1_16 + pe).permute(0, 2, 3, 1).reshape(n, h16 * w16, c)
+            t2 = (f2_16 + pe).permute(0, 2, 3, 1).reshape(n, h16 * w16, c)
+            t1, t2 = self.self_att_fn(t1, t2)
+            f1_16 = t1.reshape(n, h16, w16, c).permute(0, 3, 1, 2)
+            f2_16 = t2.reshape(n, h16, w16, c).permute(0, 3, 1, 2)
+            flow16 = torch.zeros(n, 2, h16, w16, dtype=torch.float32, device=fmap1.device)
+            _, _, up = self._stage(self.corr_cls(f1_16, f2_16, att=self.cross_att_fn), net16, inp16, flow16, off16,
+                                   self.iters // 2, False, outs)
+            # 1/(2*ds): learned offsets, no attention
+            f1_8, f2_8 = F.avg_pool2d(fmap1, 2, stride=2), F.avg_pool2d(fmap2, 2, stride=2)
+            off8 = self.range_8 * (torch.sigmoid(self.conv_offset_8(f1_8)) - 0.5) * 2.0
+            net8, inp8 = F.avg_pool2d(net, 2, stride=2), F.avg_pool2d(inp, 2, stride=2)
+            scale = f1_8.shape[2] / up.shape[2]
+            flow8 = scale * F.interpolate(up, size=f1_8.shape[2:], mode="bilinear", align_corners=True)
+            _, _, up = self._stage(self.corr_cls(f1_8, f2_8), net8, inp8, flow8, off8, self.iters // 2, False, outs)
+            scale = fmap1.shape[2] / up.shape[2]
+            flow = scale * F.interpolate(up, size=fmap1.shape[2:], mode="bilinear", align_corners=True)
+        # 1/ds: plain warped window correlation
+        _, _, up = self._stage(self.corr_cls(fmap1, fmap2), net, inp, flow, None, self.iters, True, outs)
+        if self.test_mode:
+            return up
+        return outs

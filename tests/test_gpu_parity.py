@@ -456,3 +456,26 @@ def test_cre_agcl_properties():
     assert (x - 2 * ops.agcl_corr_iter(f1, f2, flow, False)).abs().max() == 0  # scaling by 2 is exact
     with pytest.raises(Exception):
         ops.agcl_corr_iter(f1[:, :62], f2[:, :62], flow, False)  # 62 channels: not 4 groups
+
+
+def test_cre_cascade_small_golden(gold, cre_sd):
+    """a20: the whole 3-scale cascade (8 outputs: 2 at 1/32-stage, 2 at 1/16-stage, 4 at 1/8-stage resolution x8)
+    against the imported reference's outputs, and the flow_init entry (second call of the 2-stage wrapper)."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cre_stereo import CREStereoBase
+    g = gold("cre_forward.npz")
+    fr1, fr2 = weightgen.synthetic_frames(3, 1, 128, 192)
+    m = CREStereoBase(iters=4)
+    m.load_state_dict(cre_sd, strict=True)
+    m = m.to(DEV).eval()
+    outs = m(fr1.to(DEV), fr2.to(DEV))
+    assert len(outs) == 8
+    errs = [np.abs(o["up_disp"].cpu().numpy() - g[f"up_disp_{i}"]).max() for i, o in enumerate(outs)]
+    print("\ncre cascade max-abs per output:", " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) <= 1e-4
+    m.iters = 2
+    outs = m(fr1.to(DEV), fr2.to(DEV), flow_init=t(g["flow_init"]).to(DEV))
+    errs = [np.abs(o["up_disp"].cpu().numpy() - g["up_disp_init"][i]).max() for i, o in enumerate(outs)]
+    assert len(outs) == 2 and max(errs) <= 1e-4
+    m.test_mode = True
+    assert torch.equal(m(fr1.to(DEV), fr2.to(DEV), flow_init=t(g["flow_init"]).to(DEV)), outs[-1]["up_disp"])

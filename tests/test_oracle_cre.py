@@ -54,3 +54,15 @@ def test_cascade_small(gold, cre_sd):
     outs = C.cre_stereo_forward(cre_sd, fr1, fr2, 2, flow_init=t(g["flow_init"]))
     for i, o in enumerate(outs):
         assert np.abs(o.numpy() - g["up_disp_init"][i]).max() <= 2e-5, i
+
+
+def test_cre_model_state_dict_matches_spec(cre_sd):
+    """The drop-in CREStereoBase registers the reference's state_dict keys/shapes in the reference's order
+    (spec checked against the imported reference in oracle/make_golden_cre.py) and loads strictly."""
+    from nndepth_amd.cre_stereo import CREStereoBase
+    m = CREStereoBase(iters=4)
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == [(k, tuple(s)) for k, s in C.cre_stereo_spec()]
+    m.load_state_dict(cre_sd, strict=True)
+    with pytest.raises(ValueError):
+        CREStereoBase(hidden_dim=128, context_dim=64)
