@@ -3,15 +3,15 @@
 // Replaces nndepth/models/cre_stereo/cost_volume.py:28-154 and nndepth/models/cre_stereo/utils.py:5-20,34-107
 // (reference; semantics restated in oracle/cre_ref.py: bilinear_sampler / agcl_corr_iter / agcl_corr_att_offset).
 //
-// All three kernels are gather + short dot products: HBM/L2-bound, no MFMA.  Consecutive lanes are consecutive
+// The kernels are gather + short dot products: HBM/L2-bound, no MFMA.  Consecutive lanes are consecutive
 // pixels, so the left-feature loads and the output stores are coalesced and the four gathers of a tap land in the
 // one or two cache lines the neighbouring lanes touch as well (the flow field is smooth).
 //   sample      : out[n,c,p] = bilinear(img[n,c], coords[n,p])                 thread = point, loops channels
-//   window_corr : iter mode, second pass: the right features are warped ONCE by (grid + flow) with `sample`, then
-//                 out[n,g*9+k,y,x] = mean_c f1_g[c,y,x] * warped_g[c, clamp(y+dy_k), clamp(x+dx_k)]
-//                 (replicate padding of the warped map = index clamp)         thread = (pixel, group)
+//   window_corr : iter mode, second pass: the right features are warped ONCE by (grid + flow) with `sample` (4 gathers
+//                 per value instead of 36), then out[n,g*9+k,y,x] = mean_c f1_g[c,y,x] * warped_g[c, clamp(y+dy_k),
+//                 clamp(x+dx_k)] with coalesced loads only            thread = (pixel, group, channel slice)
 //   offset_corr : out[n,g*9+k,y,x] = mean_c f1_g[c,y,x] * bilinear(f2_g[c], (x,y) + flow + window_k + extra_k)
-//                 taps/weights are computed once per (pixel, k) and reused over all 4 groups   thread = (pixel, k)
+//                 9 tap sets per pixel prepared once                   thread = (pixel, group, channel slice)
 //
 // Compiled with -ffp-contract=off: the coordinate round trip pixel -> [-1,1] -> pixel and the
 // Ia*wa + Ib*wb + Ic*wc + Id*wd sum keep the reference's rounding sequence.
@@ -20,9 +20,9 @@
 namespace nnd {
 
 struct Taps {
-    int o00, o01, o10, o11;  // element offsets inside one channel plane (clamped into the image)
-    float w00, w01, w10, w11;
-    bool v00, v01, v10, v11;  // tap lies inside the image (outside = the zero border of the reference)
+    int o00, o01, o10, o11;    // element offsets inside one channel plane (clamped into the image)
+    float w00, w01, w10, w11;  // a tap outside the image (the zero border of the reference) gets weight 0 instead of
+                               // value 0: the product is the same 0 for finite features, and it costs no flag registers
 };
 
 // x, y: pixel coordinates.  utils.py:9-10 maps them to [-1,1], utils.py:55-56 (align_corners=True) maps back.
@@ -44,22 +44,25 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
     const bool yin0 = y0 >= 0 && y0 < H, yin1 = y1 >= 0 && y1 < H;
     const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
-    t.o00 = cy0 * W + cx0; t.v00 = xin0 && yin0;
-    t.o01 = cy1 * W + cx0; t.v01 = xin0 && yin1;
-    t.o10 = cy0 * W + cx1; t.v10 = xin1 && yin0;
-    t.o11 = cy1 * W + cx1; t.v11 = xin1 && yin1;
+    t.o00 = cy0 * W + cx0;
+    t.o01 = cy1 * W + cx0;
+    t.o10 = cy0 * W + cx1;
+    t.o11 = cy1 * W + cx1;
+    if (!(xin0 && yin0)) t.w00 = 0.f;
+    if (!(xin0 && yin1)) t.w01 = 0.f;
+    if (!(xin1 && yin0)) t.w10 = 0.f;
+    if (!(xin1 && yin1)) t.w11 = 0.f;
     return t;
 }
 
 __device__ __forceinline__ float tap_sum(const float* __restrict__ plane, const Taps& t) {
-    const float a = plane[t.o00], b = plane[t.o01], c = plane[t.o10], d = plane[t.o11];
-    return (t.v00 ? a : 0.f) * t.w00 + (t.v01 ? b : 0.f) * t.w01 + (t.v10 ? c : 0.f) * t.w10 + (t.v11 ? d : 0.f) * t.w11;
+    return plane[t.o00] * t.w00 + plane[t.o01] * t.w01 + plane[t.o10] * t.w10 + plane[t.o11] * t.w11;
 }
 
 // coords != nullptr: explicit sample points (N, Hg*Wg, 2).  coords == nullptr: warp by flow (N,2,H,W) on the
 // image's own grid (Hg*Wg == H*W): point (x, y) samples (x + flow_x, y + flow_y).
 // grid: (ceil(P/256), ceil(C/CPB), N)
-constexpr int SAMPLE_CPB = 32;  // channels per block
+constexpr int SAMPLE_CPB = 8;  // channels per block: 32 gathers in flight per thread
 __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ img, const float* __restrict__ coords,
                                                      const float* __restrict__ flow, float* __restrict__ out, int C,
                                                      int H, int W, int P) {
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ i
     const int c0 = blockIdx.y * SAMPLE_CPB, c1 = min(c0 + SAMPLE_CPB, C);
     const float* plane = img + ((long)n * C + c0) * H * W;
     float* o = out + ((long)n * C + c0) * P + p;
-#pragma unroll 4
+#pragma unroll 8
     for (int c = c0; c < c1; ++c) {
         *o = tap_sum(plane, t);
         plane += (long)H * W;
@@ -98,12 +101,18 @@ __device__ __forceinline__ void window_offset(int k, bool small_patch, int& dy, 
     }
 }
 
-// grid: (ceil(HW/256), 4 groups, N).  G = C/4 channels per group.
+// ITER mode, second pass (the right features were warped once by `sample_kernel` into a scratch map):
+//   out[n,g*9+k,y,x] = mean_c f1_g[c,y,x] * warped_g[c, clamp(y+dy_k), clamp(x+dx_k)]     (replicate padding = index clamp)
+// Block = 64 consecutive pixels x 4 waves; blockIdx.y = channel group; the 4 waves split the group's channels into 4
+// slices and their 9 partial sums meet in LDS.  All loads are coalesced (a wave reads 64 consecutive pixels, shifted).
+// grid: (ceil(HW/64), 4 groups, N)
 __global__ void __launch_bounds__(256) window_corr_kernel(const float* __restrict__ f1, const float* __restrict__ warped,
                                                           float* __restrict__ out, int C, int H, int W, int small_patch) {
+    __shared__ float red[3][9][64];
     const int HW = H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const bool p_ok = (int)blockIdx.x * 64 + lane < HW;
+    const int p = min((int)blockIdx.x * 64 + lane, HW - 1);  // tail lanes redo the last pixel: no exit before the barrier
     const int g = blockIdx.y, n = blockIdx.z, G = C / 4;
     const int y = p / W, x = p - y * W;
     int off[9];
@@ -113,52 +122,83 @@ __global__ void __launch_bounds__(256) window_corr_kernel(const float* __restric
         window_offset(k, small_patch != 0, dy, dx);
         off[k] = min(max(y + dy, 0), H - 1) * W + min(max(x + dx, 0), W - 1);
     }
+    const int per = (G + 3) / 4, c0 = slice * per, c1 = min(c0 + per, G);
+    const float* l = f1 + ((long)n * C + (long)g * G + c0) * HW + p;
+    const float* r = warped + ((long)n * C + (long)g * G + c0) * HW;
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    const float* l = f1 + ((long)n * C + (long)g * G) * HW;
-    const float* r = warped + ((long)n * C + (long)g * G) * HW;
-    for (int c = 0; c < G; ++c) {
-        const float lv = l[p];
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+        const float lv = *l;
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] += lv * r[off[k]];
         l += HW;
         r += HW;
     }
-    float* o = out + ((long)n * 36 + g * 9) * HW + p;
-    const float inv = (float)G;
+    if (slice > 0) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[(long)k * HW] = acc[k] / inv;
+        for (int k = 0; k < 9; ++k) red[slice - 1][k][lane] = acc[k];
+    }
+    __syncthreads();
+    if (slice == 0 && p_ok) {
+        const float inv = (float)G;
+        float* o = out + ((long)n * 36 + g * 9) * HW + p;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[(long)k * HW] = (((acc[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane]) / inv;
+    }
 }
 
-// grid: (ceil(HW/256), 9 window positions, N)
-__global__ void __launch_bounds__(256) offset_corr_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                          const float* __restrict__ flow, const float* __restrict__ extra,
-                                                          float* __restrict__ out, int C, int H, int W, int small_patch) {
+// OFFSET mode: position k samples (x, y) + flow(x, y) + window_k + extra_k(x, y): every (pixel, k) has its own
+// sub-pixel position, so nothing can be shared — 9*4 gathers per pixel and channel, bound by the texture-address
+// rate, not by HBM.  Same block shape as above; a thread prepares the 9 tap sets of its pixel once.
+// grid: (ceil(HW/64), 4 groups, N)
+__global__ void __launch_bounds__(256, 3) offset_corr_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                             const float* __restrict__ flow, const float* __restrict__ extra,
+                                                             float* __restrict__ out, int C, int H, int W, int small_patch) {
+    __shared__ float red[3][9][64];
     const int HW = H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const int k = blockIdx.y, n = blockIdx.z, G = C / 4;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const bool p_ok = (int)blockIdx.x * 64 + lane < HW;
+    const int p = min((int)blockIdx.x * 64 + lane, HW - 1);
+    const int g = blockIdx.y, n = blockIdx.z, G = C / 4;
     const int y = p / W, x = p - y * W;
-    int dy, dx;
-    window_offset(k, small_patch != 0, dy, dx);
-    // reference order (cost_volume.py:136-141): offsets = window + extra; coords = (grid + flow) + offsets
-    const float ex = extra[((long)n * 18 + 2 * k) * HW + p], ey = extra[((long)n * 18 + 2 * k + 1) * HW + p];
-    const float sx = ((float)x + flow[((long)n * 2 + 0) * HW + p]) + ((float)dx + ex);
-    const float sy = ((float)y + flow[((long)n * 2 + 1) * HW + p]) + ((float)dy + ey);
-    const Taps t = make_taps(sx, sy, H, W);
-    const float* l = f1 + (long)n * C * HW + p;
-    const float* r = f2 + (long)n * C * HW;
-    const float inv = (float)G;
-    for (int g = 0; g < 4; ++g) {
-        float acc = 0.f;
-#pragma unroll 4
-        for (int c = 0; c < G; ++c) {
-            acc += *l * tap_sum(r, t);
-            l += HW;
-            r += HW;
-        }
-        out[((long)n * 36 + g * 9 + k) * HW + p] = acc / inv;
+    const float* fl = flow + (long)n * 2 * HW;
+    Taps t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        int dy, dx;
+        window_offset(k, small_patch != 0, dy, dx);
+        // reference order (cost_volume.py:136-141): offsets = window + extra; coords = (grid + flow) + offsets
+        const float ex = extra[((long)n * 18 + 2 * k) * HW + p], ey = extra[((long)n * 18 + 2 * k + 1) * HW + p];
+        const float sx = ((float)x + fl[p]) + ((float)dx + ex);
+        const float sy = ((float)y + fl[HW + p]) + ((float)dy + ey);
+        t[k] = make_taps(sx, sy, H, W);
+    }
+    const int per = (G + 3) / 4, c0 = slice * per, c1 = min(c0 + per, G);
+    const float* l = f1 + ((long)n * C + (long)g * G + c0) * HW + p;
+    const float* r = f2 + ((long)n * C + (long)g * G + c0) * HW;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+#pragma unroll 1
+    for (int c = c0; c < c1; ++c) {
+        const float lv = *l;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] += lv * tap_sum(r, t[k]);
+        l += HW;
+        r += HW;
+    }
+    if (slice > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[slice - 1][k][lane] = acc[k];
+    }
+    __syncthreads();
+    if (slice == 0 && p_ok) {
+        const float inv = (float)G;
+        float* o = out + ((long)n * 36 + g * 9) * HW + p;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[(long)k * HW] = (((acc[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane]) / inv;
     }
 }
 
@@ -197,8 +237,8 @@ int nnd_agcl_corr_iter(const float* fmap1, const float* fmap2, const float* flow
     hipLaunchKernelGGL(sample_kernel, dim3(cdiv(HW, 256), cdiv(C, SAMPLE_CPB), N), dim3(256), 0, s, fmap2,
                        (const float*)nullptr, flow, warped, C, H, W, HW);
     NND_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_corr_kernel, dim3(cdiv(HW, 256), 4, N), dim3(256), 0, s, fmap1, (const float*)warped, out, C,
-                       H, W, small_patch);
+    hipLaunchKernelGGL(window_corr_kernel, dim3(cdiv(HW, 64), 4, N), dim3(256), 0, s, fmap1, (const float*)warped, out, C, H, W,
+                       small_patch);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
@@ -208,8 +248,8 @@ int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* fl
     NND_REQUIRE(fmap1 && fmap2 && flow && extra_offset && out, "agcl_corr_offset: null pointer");
     int rc = check_agcl("agcl_corr_offset", N, C, H, W);
     if (rc != NND_OK) return rc;
-    hipLaunchKernelGGL(offset_corr_kernel, dim3(cdiv(H * W, 256), 9, N), dim3(256), 0, (hipStream_t)stream, fmap1, fmap2,
-                       flow, extra_offset, out, C, H, W, small_patch);
+    hipLaunchKernelGGL(offset_corr_kernel, dim3(cdiv(H * W, 64), 4, N), dim3(256), 0, (hipStream_t)stream, fmap1, fmap2, flow,
+                       extra_offset, out, C, H, W, small_patch);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

@@ -111,7 +111,7 @@ __device__ __forceinline__ float tanhf_(float v) {
 
 // NE: patch elements staged per thread per super-chunk (the thread owns one patch position and NE channels)
 template <int KH, int KW, int CI_T, int P, int NE>
-__global__ void __launch_bounds__(512) conv_mfma_kernel(ConvArgs a) {
+__global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArgs a) {
     constexpr int NT = KH * KW;
     constexpr int SG = CI_T < 32 ? CI_T : 32;  // channels per pipeline step
     constexpr int NGRP = CI_T / SG;            // channel groups per tap
@@ -424,16 +424,17 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
     double best = 1e30;
     bool found = false;
     for (int ks : {1, 2})
-    for (int wco : {4, 3, 2, 1}) {
+    for (int wco : {8, 6, 4, 3, 2, 1}) {
         if (force_ks > 0 && ks != force_ks) continue;
         if (force_wco > 0 && wco != force_wco) continue;
-        if (ks > L.nchunks || wco * ks > 8) continue;
+        if (ks > L.nchunks || wco * ks > 12) continue;  // P = 1 kernels are built for <= 768 threads, P = 2 for <= 512
         if (c1 > 0 && c0 % (ks * L.CI_T) != 0) continue;
         if (wco > 1 && cdiv(L.ncb, wco) * wco >= L.ncb + wco) continue;  // a whole workgroup of idle waves
         const int nthreads = 64 * wco * ks;
         {
             for (int P : {1, 2}) {
                 if (force_p > 0 && P != force_p) continue;
+                if (P == 2 && wco * ks > 8) continue;
                 const int SC = NND_SC, SR = 32 / NND_SC;
                 int tx = cdiv(W, P * SC), ty = cdiv(H, SR);
                 int PR = SR + L.KH - 1, PC = P * SC + L.KW - 1;
@@ -447,7 +448,7 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
                 size_t red = ks > 1 ? (size_t)wco * ks * P * 1024 * sizeof(float) : 0;
                 if (red > lds) lds = red;
                 if (lds > 160 * 1024) continue;
-                int occ = P == 1 ? 4 : 2;  // resident waves per SIMD the register budget allows
+                int occ = P == 1 ? (ne <= 8 ? 4 : 3) : 2;  // resident waves per SIMD the register budget allows
                 int wg_per_cu = (int)((160 * 1024) / lds);
                 int occ_lds = cdiv(wg_per_cu * wco * ks, 4);
                 if (occ_lds < occ) occ = occ_lds;

@@ -45,6 +45,7 @@ static void make_layout(int B, int H, int W, int stored_levels, PyrLayout* L, in
 // grid: (ceil(W/32) w1-blocks, H, B); block: 256 threads = 4 waves, wave t takes w2 tiles t, t+4, ...
 // Group-wise variant (IGEV, igev_stereo/cost_volume.py:81-98): blockIdx.z = b*G + g, the dot product runs over
 // the C channels [g*C, (g+1)*C) of a Ctot-channel map; pyramid rows are ordered (b, g, h, w1).  RAFT: G = 1.
+template <int KB>
 __global__ void __launch_bounds__(256) corr1d_build_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                            float* __restrict__ pyr, PyrLayout L, int C, int H, int W,
                                                            float rscale_div, int Ctot, int G) {
@@ -64,12 +65,35 @@ __global__ void __launch_bounds__(256) corr1d_build_kernel(const float* __restri
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < C; c += 2) {
-            const int cc = c + h2;
-            float av = (a_ok && cc < C) ? a_base[cc * HW + w1] : 0.f;
-            float bv = (b_ok && cc < C) ? b_base[cc * HW + w2] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        // K loop in batches of KB k-steps (2 channels each), double-buffered: the 2*KB loads of batch i+1 are in flight
+        // while the KB MFMAs of batch i issue (one wave per SIMD here, so latency is hidden by depth, not occupancy).
+        // Loads are unconditional on clamped indices; the zero-fill select happens when the batch is consumed.
+        const int w1c = min(w1, W - 1), w2c = min(w2, W - 1);
+        const int nk = (C + 1) / 2, nbatch = (nk + KB - 1) / KB;
+        float av[2][KB], bv[2][KB];
+        auto load = [&](int bt, float* a, float* bb) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                const int cc = min((bt * KB + i) * 2 + h2, C - 1);
+                a[i] = a_base[cc * HW + w1c];
+                bb[i] = b_base[cc * HW + w2c];
+            }
+        };
+        auto mma = [&](int bt, const float* a, const float* bb) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                const bool k_ok = (bt * KB + i) * 2 + h2 < C;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && k_ok) ? a[i] : 0.f, (b_ok && k_ok) ? bb[i] : 0.f, acc, 0, 0, 0);
+            }
+        };
+        load(0, av[0], bv[0]);
+        for (int bt = 0; bt < nbatch; bt += 2) {
+            if (bt + 1 < nbatch) load(bt + 1, av[1], bv[1]);
+            mma(bt, av[0], bv[0]);
+            if (bt + 1 < nbatch) {
+                if (bt + 2 < nbatch) load(bt + 2, av[0], bv[0]);
+                mma(bt + 1, av[1], bv[1]);
+            }
         }
         // D[i = w1 row][j = w2 col]: lane holds column w2, rows (reg&3)+8*(reg>>2)+4*h2
 #pragma unroll
@@ -277,7 +301,10 @@ int nnd_corr1d_build(const float* fmap1, const float* fmap2, float* pyramid, int
     make_layout(B, H, W, num_levels + 1, &L, nullptr);
     dim3 grid(cdiv(W, 32), H, B), block(256);
     float div = (float)sqrt((double)C);
-    hipLaunchKernelGGL(corr1d_build_kernel, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, C, H, W, div, C, 1);
+    if (C >= 64)
+        hipLaunchKernelGGL(corr1d_build_kernel<32>, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, C, H, W, div, C, 1);
+    else
+        hipLaunchKernelGGL(corr1d_build_kernel<4>, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, C, H, W, div, C, 1);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
@@ -292,8 +319,12 @@ int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid,
     make_layout(B * num_groups, H, W, num_levels + 1, &L, nullptr);
     dim3 grid(cdiv(W, 32), H, B * num_groups), block(256);
     float div = (float)sqrt((double)group_channels);
-    hipLaunchKernelGGL(corr1d_build_kernel, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, group_channels, H, W,
-                       div, Ctot, num_groups);
+    if (group_channels >= 64)
+        hipLaunchKernelGGL(corr1d_build_kernel<32>, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, group_channels,
+                           H, W, div, Ctot, num_groups);
+    else
+        hipLaunchKernelGGL(corr1d_build_kernel<4>, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, group_channels,
+                           H, W, div, Ctot, num_groups);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
