@@ -186,6 +186,19 @@ int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packe
                            float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                            float* workspace, int B, int H, int W, int rate, int iters, void* stream);
 
+/* CREStereo variant of the loop — one stage of the cascade (nndepth/models/cre_stereo/model.py:221-236, 246-259, 270-284):
+ * every iteration: AGCL correlation of (fmap1, fmap2) at the current flow -> update block (flow_channels = 2) ->
+ * flow += delta -> 2-channel convex upsample.  Iteration i searches a 1x9 window when i is even, 3x3 when odd.
+ * extra_offset == NULL: iter mode (nnd_agcl_corr_iter; `warped` = caller-owned scratch of B*C*H*W floats);
+ * extra_offset (B,18,H,W): offset mode (nnd_agcl_corr_offset; fmap1/fmap2 already attended by the caller; `warped`
+ * may be NULL).  flow_init (B,2,H,W) or NULL for zero.  up_out: iteration i writes (B,2,rate*H,rate*W) at
+ * up_out + i*up_iter_stride; low_out (optional) the final flow (B,2,H,W); net_out (optional) the hidden state.   */
+int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
+                          const float* fmap1, const float* fmap2, int C, const float* extra_offset, float* warped,
+                          const float* net, const float* inp, const float* flow_init,
+                          float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
+                          float* workspace, int B, int H, int W, int rate, int iters, void* stream);
+
 /* ------------------------------------------------------------------------------ profiling
  * Times `reps` back-to-back launches of ONE hot-path conv (selected by `which`, see
  * nnd_conv_name) on `stream` with hipEvents recorded on that same stream and returns the

@@ -49,6 +49,8 @@ SIGNATURES = {
                                     _I, _I, _I, _I, _I, _P]),
     "nnd_igev_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
+    "nnd_cre_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
+                                   _I, _I, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
                               C.POINTER(C.c_double)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),

@@ -87,6 +87,7 @@ class AGCL:
         self.fmap2 = fmap2.float().contiguous()
         self.att = att
         self._scratch = None  # warped right features of iter mode, reused over the iterations
+        self._attended = None  # att(fmap1, fmap2): constant over the iterations of a stage (inference), computed once
 
     def __call__(self, flow: torch.Tensor, extra_offset: torch.Tensor, small_patch: bool = False,
                  iter_mode: bool = False) -> torch.Tensor:
@@ -94,12 +95,19 @@ class AGCL:
             if self._scratch is None:
                 self._scratch = torch.empty_like(self.fmap2)
             return ops.agcl_corr_iter(self.fmap1, self.fmap2, flow.float(), small_patch, self._scratch)
-        f1, f2 = self.fmap1, self.fmap2
-        if self.att is not None:
-            N, C, H, W = f1.shape
-            a = f1.permute(0, 2, 3, 1).reshape(N, H * W, C)
-            b = f2.permute(0, 2, 3, 1).reshape(N, H * W, C)
-            a, b = self.att(a, b)
-            f1 = a.reshape(N, H, W, C).permute(0, 3, 1, 2)
-            f2 = b.reshape(N, H, W, C).permute(0, 3, 1, 2)
+        f1, f2 = self.attended()
         return ops.agcl_corr_offset(f1, f2, flow.float(), extra_offset.float(), small_patch)
+
+    def attended(self):
+        """(fmap1, fmap2) after the optional cross attention (cost_volume.py:92-101).  The reference re-evaluates `att`
+        on the same two maps in every iteration; at inference the result is the same each time, so it is cached."""
+        if self.att is None:
+            return self.fmap1, self.fmap2
+        if self._attended is None:
+            N, C, H, W = self.fmap1.shape
+            a = self.fmap1.permute(0, 2, 3, 1).reshape(N, H * W, C)
+            b = self.fmap2.permute(0, 2, 3, 1).reshape(N, H * W, C)
+            a, b = self.att(a, b)
+            self._attended = (a.reshape(N, H, W, C).permute(0, 3, 1, 2).float().contiguous(),
+                              b.reshape(N, H, W, C).permute(0, 3, 1, 2).float().contiguous())
+        return self._attended

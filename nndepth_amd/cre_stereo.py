@@ -9,6 +9,8 @@ nndepth/models/cre_stereo/model.py:17-288.  Inside `forward()`:
     AGCL (warp + window correlation, offset sampling)     HIP  csrc/agcl.hip          model.py:204-206,229,252,277
     update block (2-channel flow)                         HIP  csrc/update_block.hip  model.py:231,254,279
     convex upsample (2-channel)                           HIP  csrc/corr1d.hip        model.py:234,257,282
+  each stage of the cascade is ONE C-ABI call (`nnd_cre_stereo_refine`: all its iterations enqueued as a 3-stream
+  DAG); `fused_loop=False` keeps the reference's seam-by-seam loop, every step still a HIP kernel.
 
 The three stages of the cascade (1/32, 1/16 and 1/8 of the image for fnet_ds = 8) run `iters//2`, `iters//2` and
 `iters` update iterations; even iterations search a 1x9 window, odd ones a 3x3 window.
@@ -93,7 +95,8 @@ class CREStereoBase(nn.Module):
     def __init__(self, fnet_cls: str = "basic_encoder", update_cls: str = "basic_update_block", iters: int = 12,
                  max_disp: int = 192, num_fnet_channels: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  search_num: int = 9, mixed_precision: bool = False, test_mode: bool = False, tracing: bool = False,
-                 include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True, **kwargs):
+                 include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
+                 fused_loop: bool = True, **kwargs):
         super().__init__()
         if fnet_cls != "basic_encoder" or update_cls != "basic_update_block":
             raise ValueError("CREStereoBase: only basic_encoder / basic_update_block exist (as in the reference)")
@@ -104,6 +107,7 @@ class CREStereoBase(nn.Module):
         self.max_flow, self.mixed_precision, self.test_mode, self.iters = max_disp, mixed_precision, test_mode, iters
         self.hidden_dim, self.context_dim, self.search_num = hidden_dim, context_dim, search_num
         self.tracing, self.include_preprocessing = tracing, include_preprocessing
+        self.fused_loop = fused_loop
         self.fnet = BasicEncoder(output_dim=num_fnet_channels, norm_fn="instance", dropout=0)
         self.fnet_ds = 8
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=4 * 9, flow_channel=2,
@@ -122,6 +126,14 @@ class CREStereoBase(nn.Module):
         return convex_upsample(flow, mask, rate)
 
     def _stage(self, corr_fn, net, inp, flow, offset, n_iters: int, iter_mode: bool, outs: List[Dict[str, torch.Tensor]]):
+        if self.fused_loop and isinstance(corr_fn, AGCL) and n_iters > 0:
+            # ONE C-ABI call for the whole stage (nnd_cre_stereo_refine): AGCL + update block + advance + upsample
+            eng = self.update_block.sync_engine(net.device)
+            f1, f2 = corr_fn.attended()
+            up, flow, net = eng.refine_cre(f1, f2, net.float(), inp.float(), self.fnet_ds, n_iters, flow_init=flow,
+                                           extra_offset=None if iter_mode else offset.float())
+            outs.extend({"up_disp": up[i]} for i in range(n_iters))
+            return net, flow, up[n_iters - 1]
         up = None
         for itr in range(n_iters):
             corr = corr_fn(flow, offset, small_patch=(itr % 2 == 1), iter_mode=iter_mode)

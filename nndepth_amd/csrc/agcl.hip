@@ -16,6 +16,7 @@
 // Compiled with -ffp-contract=off: the coordinate round trip pixel -> [-1,1] -> pixel and the
 // Ia*wa + Ib*wb + Ic*wc + Id*wd sum keep the reference's rounding sequence.
 #include "common.h"
+#include "layout.h"
 
 namespace nnd {
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ float tap_sum(const float* __restrict__ plane, const 
 constexpr int SAMPLE_CPB = 8;  // channels per block: 32 gathers in flight per thread
 __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ img, const float* __restrict__ coords,
                                                      const float* __restrict__ flow, float* __restrict__ out, int C,
-                                                     int H, int W, int P) {
+                                                     int H, int W, int P, Lay fl_lay) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const int n = blockIdx.z;
@@ -76,8 +77,9 @@ __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ i
         y = xy.y;
     } else {
         const int py = p / W, px = p - py * W;
-        x = (float)px + flow[((long)n * 2 + 0) * P + p];
-        y = (float)py + flow[((long)n * 2 + 1) * P + p];
+        const long fo = pix_off(fl_lay, py, px);
+        x = (float)px + flow[((long)n * 2 + 0) * fl_lay.plane + fo];
+        y = (float)py + flow[((long)n * 2 + 1) * fl_lay.plane + fo];
     }
     const Taps t = make_taps(x, y, H, W);
     const int c0 = blockIdx.y * SAMPLE_CPB, c1 = min(c0 + SAMPLE_CPB, C);
@@ -107,7 +109,8 @@ __device__ __forceinline__ void window_offset(int k, bool small_patch, int& dy, 
 // slices and their 9 partial sums meet in LDS.  All loads are coalesced (a wave reads 64 consecutive pixels, shifted).
 // grid: (ceil(HW/64), 4 groups, N)
 __global__ void __launch_bounds__(256) window_corr_kernel(const float* __restrict__ f1, const float* __restrict__ warped,
-                                                          float* __restrict__ out, int C, int H, int W, int small_patch) {
+                                                          float* __restrict__ out, int C, int H, int W, int small_patch,
+                                                          Lay out_lay) {
     __shared__ float red[3][9][64];
     const int HW = H * W;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -143,9 +146,9 @@ __global__ void __launch_bounds__(256) window_corr_kernel(const float* __restric
     __syncthreads();
     if (slice == 0 && p_ok) {
         const float inv = (float)G;
-        float* o = out + ((long)n * 36 + g * 9) * HW + p;
+        float* o = out + ((long)n * 36 + g * 9) * out_lay.plane + pix_off(out_lay, y, x);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) o[(long)k * HW] = (((acc[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane]) / inv;
+        for (int k = 0; k < 9; ++k) o[(long)k * out_lay.plane] = (((acc[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane]) / inv;
     }
 }
 
@@ -155,7 +158,8 @@ __global__ void __launch_bounds__(256) window_corr_kernel(const float* __restric
 // grid: (ceil(HW/64), 4 groups, N)
 __global__ void __launch_bounds__(256, 3) offset_corr_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                              const float* __restrict__ flow, const float* __restrict__ extra,
-                                                             float* __restrict__ out, int C, int H, int W, int small_patch) {
+                                                             float* __restrict__ out, int C, int H, int W, int small_patch,
+                                                             Lay fl_lay, Lay out_lay) {
     __shared__ float red[3][9][64];
     const int HW = H * W;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -163,7 +167,8 @@ __global__ void __launch_bounds__(256, 3) offset_corr_kernel(const float* __rest
     const int p = min((int)blockIdx.x * 64 + lane, HW - 1);
     const int g = blockIdx.y, n = blockIdx.z, G = C / 4;
     const int y = p / W, x = p - y * W;
-    const float* fl = flow + (long)n * 2 * HW;
+    const float* fl = flow + (long)n * 2 * fl_lay.plane + pix_off(fl_lay, y, x);
+    const float flx = fl[0], fly = fl[fl_lay.plane];
     Taps t[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -171,8 +176,8 @@ __global__ void __launch_bounds__(256, 3) offset_corr_kernel(const float* __rest
         window_offset(k, small_patch != 0, dy, dx);
         // reference order (cost_volume.py:136-141): offsets = window + extra; coords = (grid + flow) + offsets
         const float ex = extra[((long)n * 18 + 2 * k) * HW + p], ey = extra[((long)n * 18 + 2 * k + 1) * HW + p];
-        const float sx = ((float)x + fl[p]) + ((float)dx + ex);
-        const float sy = ((float)y + fl[HW + p]) + ((float)dy + ey);
+        const float sx = ((float)x + flx) + ((float)dx + ex);
+        const float sy = ((float)y + fly) + ((float)dy + ey);
         t[k] = make_taps(sx, sy, H, W);
     }
     const int per = (G + 3) / 4, c0 = slice * per, c1 = min(c0 + per, G);
@@ -196,9 +201,9 @@ __global__ void __launch_bounds__(256, 3) offset_corr_kernel(const float* __rest
     __syncthreads();
     if (slice == 0 && p_ok) {
         const float inv = (float)G;
-        float* o = out + ((long)n * 36 + g * 9) * HW + p;
+        float* o = out + ((long)n * 36 + g * 9) * out_lay.plane + pix_off(out_lay, y, x);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) o[(long)k * HW] = (((acc[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane]) / inv;
+        for (int k = 0; k < 9; ++k) o[(long)k * out_lay.plane] = (((acc[k] + red[0][k][lane]) + red[1][k][lane]) + red[2][k][lane]) / inv;
     }
 }
 
@@ -208,6 +213,31 @@ static int check_agcl(const char* what, int N, int C, int H, int W) {
     NND_REQUIRE((long)C * H * W < (1L << 31), "%s: plane offsets exceed 32 bits", what);
     return NND_OK;
 }
+
+
+int agcl_iter_launch(const float* f1, const float* f2, const float* flow, float* warped, float* out, int N, int C, int H,
+                     int W, int small_patch, hipStream_t s, bool tiled) {
+    const int HW = H * W;
+    const Lay lay = make_lay(H, W, tiled);
+    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(HW, 256), cdiv(C, SAMPLE_CPB), N), dim3(256), 0, s, f2, (const float*)nullptr,
+                       flow, warped, C, H, W, HW, lay);
+    NND_LAUNCH_CHECK();
+    hipLaunchKernelGGL(window_corr_kernel, dim3(cdiv(HW, 64), 4, N), dim3(256), 0, s, f1, (const float*)warped, out, C, H, W,
+                       small_patch, lay);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int agcl_offset_launch(const float* f1, const float* f2, const float* flow, const float* extra, float* out, int N, int C, int H,
+                       int W, int small_patch, hipStream_t s, bool tiled) {
+    const Lay lay = make_lay(H, W, tiled);
+    hipLaunchKernelGGL(offset_corr_kernel, dim3(cdiv(H * W, 64), 4, N), dim3(256), 0, s, f1, f2, flow, extra, out, C, H, W,
+                       small_patch, lay, lay);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int agcl_check(const char* what, int N, int C, int H, int W) { return check_agcl(what, N, C, H, W); }
 
 }  // namespace nnd
 
@@ -222,7 +252,7 @@ int nnd_bilinear_sample(const float* img, const float* coords, float* out, int N
     const int P = Hg * Wg;
     dim3 grid(cdiv(P, 256), cdiv(C, SAMPLE_CPB), N);
     hipLaunchKernelGGL(sample_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, coords, (const float*)nullptr, out, C, H,
-                       W, P);
+                       W, P, make_lay(H, W, false));
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
@@ -232,15 +262,7 @@ int nnd_agcl_corr_iter(const float* fmap1, const float* fmap2, const float* flow
     NND_REQUIRE(fmap1 && fmap2 && flow && warped && out, "agcl_corr_iter: null pointer");
     int rc = check_agcl("agcl_corr_iter", N, C, H, W);
     if (rc != NND_OK) return rc;
-    const int HW = H * W;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(HW, 256), cdiv(C, SAMPLE_CPB), N), dim3(256), 0, s, fmap2,
-                       (const float*)nullptr, flow, warped, C, H, W, HW);
-    NND_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_corr_kernel, dim3(cdiv(HW, 64), 4, N), dim3(256), 0, s, fmap1, (const float*)warped, out, C, H, W,
-                       small_patch);
-    NND_LAUNCH_CHECK();
-    return NND_OK;
+    return agcl_iter_launch(fmap1, fmap2, flow, warped, out, N, C, H, W, small_patch, (hipStream_t)stream, false);
 }
 
 int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* flow, const float* extra_offset, float* out,
@@ -248,10 +270,7 @@ int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* fl
     NND_REQUIRE(fmap1 && fmap2 && flow && extra_offset && out, "agcl_corr_offset: null pointer");
     int rc = check_agcl("agcl_corr_offset", N, C, H, W);
     if (rc != NND_OK) return rc;
-    hipLaunchKernelGGL(offset_corr_kernel, dim3(cdiv(H * W, 64), 4, N), dim3(256), 0, (hipStream_t)stream, fmap1, fmap2, flow,
-                       extra_offset, out, C, H, W, small_patch);
-    NND_LAUNCH_CHECK();
-    return NND_OK;
+    return agcl_offset_launch(fmap1, fmap2, flow, extra_offset, out, N, C, H, W, small_patch, (hipStream_t)stream, false);
 }
 
 }  // extern "C"

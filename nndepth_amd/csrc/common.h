@@ -100,8 +100,14 @@ int convex_upsample_launch(const float* flow, const float* mask, float* out, int
                            hipStream_t stream, bool tiled);
 
 // mask_upsample.hip: fused mask.2 (1x1, x0.25) + softmax + convex upsample (mask never written)
+// CREStereo AGCL (agcl.hip).  tiled: `flow` (in) and `out` are tile-major workspace tensors; fmaps / extra / warped are NCHW.
+int agcl_iter_launch(const float* f1, const float* f2, const float* flow, float* warped, float* out, int N, int C, int H,
+                     int W, int small_patch, hipStream_t s, bool tiled);
+int agcl_offset_launch(const float* f1, const float* f2, const float* flow, const float* extra, float* out, int N, int C, int H,
+                       int W, int small_patch, hipStream_t s, bool tiled);
+int agcl_check(const char* what, int N, int C, int H, int W);
 bool mask_upsample_supported(int rate, int cin, int flow_channels);
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream, bool tiled);
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1);
 
 }  // namespace nnd

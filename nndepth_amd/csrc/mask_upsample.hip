@@ -24,9 +24,9 @@ struct MaskUpArgs {
     long xbs;
     const float* wpk;
     const float* bias;
-    const float* flow;  // (B,1,H,W)
-    float* out;         // (B,1,R*H,R*W)
-    int H, W, tiles_x;
+    const float* flow;  // (B,FC,H,W)
+    float* out;         // (B,FC,R*H,R*W)
+    int H, W, tiles_x, fc;  // fc: flow channels, 1 (RAFT/IGEV disparity) or 2 (CREStereo flow)
     Lay lay;  // layout of x and flow (tile-major inside the loop, NCHW through the C-ABI)
 };
 
@@ -40,7 +40,7 @@ struct MaskUpCfg {
     static constexpr int NT = 64 * NWAVES;
     static constexpr int NST = CIN / 32;                 // 32-channel steps over K
     static constexpr int MT_STRIDE = 33;
-    static constexpr int LDS_FLOATS = (CIN * 32 > COUT * MT_STRIDE ? CIN * 32 : COUT * MT_STRIDE) + 64;
+    static constexpr int LDS_FLOATS = (CIN * 32 > COUT * MT_STRIDE ? CIN * 32 : COUT * MT_STRIDE) + 128;
 };
 
 template <int RATE, int CIN>
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     extern __shared__ float lds[];
     float* xs = lds;                          // [CIN][32]   (K loop)
     float* mt = lds;                          // [COUT][33]  (after the K loop; aliases xs)
-    float* fp = lds + Cfg::LDS_FLOATS - 64;   // [6][10] flow patch, zero outside the image
+    float* fp = lds + Cfg::LDS_FLOATS - 128;  // [fc][6][10] flow patch, zero outside the image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,10 +86,11 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             const bool ok = (ty0 + (px >> 3)) < H && (tx0 + (px & 7)) < W;
             if (e < CIN * 32) xs[e] = ok ? v[i] : 0.f;
         }
-        if (tid < 60) {
-            const int pr = tid / 10, pc = tid % 10;
+        if (tid < 60 * a.fc) {
+            const int f = tid / 60, pos = tid % 60;
+            const int pr = pos / 10, pc = pos % 10;
             const int y = ty0 + pr - 1, x = tx0 + pc - 1;
-            fp[tid] = (y >= 0 && y < H && x >= 0 && x < W) ? a.flow[b * XP + pix_off(a.lay, y, x)] : 0.f;
+            fp[tid] = (y >= 0 && y < H && x >= 0 && x < W) ? a.flow[(b * a.fc + f) * XP + pix_off(a.lay, y, x)] : 0.f;
         }
     }
     __syncthreads();
@@ -183,10 +184,14 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             m[k] = expf(m[k] - mx);
             sum += m[k];
         }
-        float o = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) o += (m[k] / sum) * ((float)RATE * fp[(rr + k / 3) * 10 + c + k % 3]);
-        if (y < H && x < W) a.out[(long)b * HW * RATE * RATE + ((long)y * RATE + i) * OW + (long)x * RATE + j] = o;
+        for (int k = 0; k < 9; ++k) m[k] = m[k] / sum;
+        for (int f = 0; f < a.fc; ++f) {
+            float o = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o += m[k] * ((float)RATE * fp[f * 60 + (rr + k / 3) * 10 + c + k % 3]);
+            if (y < H && x < W) a.out[((long)b * a.fc + f) * HW * RATE * RATE + ((long)y * RATE + i) * OW + (long)x * RATE + j] = o;
+        }
     }
 }
 
@@ -209,16 +214,17 @@ static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
 }
 
 bool mask_upsample_supported(int rate, int cin, int flow_channels) {
-    return flow_channels == 1 && ((rate == 8 && (cin == 256 || cin == 128)) || (rate == 4 && (cin == 256 || cin == 128)));
+    return (flow_channels == 1 || flow_channels == 2) && ((rate == 8 && (cin == 256 || cin == 128)) || (rate == 4 && (cin == 256 || cin == 128)));
 }
 
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream, bool tiled) {
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels) {
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == 128 && L.Cout == 9 * rate * rate, "mask_upsample: layer shape");
-    NND_REQUIRE(mask_upsample_supported(rate, L.Cin, 1), "mask_upsample: rate %d / Cin %d not built", rate, L.Cin);
+    NND_REQUIRE(mask_upsample_supported(rate, L.Cin, flow_channels), "mask_upsample: rate %d / Cin %d / %d flow channels not built",
+                rate, L.Cin, flow_channels);
     MaskUpArgs a;
     a.x = x; a.xbs = xbs; a.wpk = blob + L.w_off; a.bias = blob + L.b_off; a.flow = flow; a.out = out;
-    a.H = H; a.W = W; a.tiles_x = cdiv(W, 8);
+    a.H = H; a.W = W; a.tiles_x = cdiv(W, 8); a.fc = flow_channels;
     a.lay = make_lay(H, W, tiled);
     if (rate == 8 && L.Cin == 256) return launch_mu<8, 256>(a, B, stream);
     if (rate == 8 && L.Cin == 128) return launch_mu<8, 128>(a, B, stream);

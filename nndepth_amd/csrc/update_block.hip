@@ -276,7 +276,11 @@ __global__ void __launch_bounds__(256) flow_head2_kernel(const float* __restrict
         if (y < H && xx < W) {
             const long pix = pix_off(lay, y, xx);
             delta[(b * FC + f) * HW + pix] = sum;
-            if (advance) {  // FC == 1 on this path
+            if (advance == 2) {  // CREStereo: the state is the flow itself (cre_stereo/model.py:281), any FC
+                const float fl = flow[(b * FC + f) * HW + pix] + sum;
+                flow[(b * FC + f) * HW + pix] = fl;
+                hx_flow[b * hx_bs + f * HW + pix] = fl;
+            } else if (advance) {  // FC == 1 on this path
                 const float cnew = coords[b * HW + pix] + sum;
                 const float fl = absolute ? cnew : cnew - (float)xx;
                 coords[b * HW + pix] = cnew;
@@ -414,7 +418,8 @@ static int run_convf1(const Plan& p, const float* blob, const float* flow, int64
     return debug_sync("encoder.convf1", s);
 }
 
-static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta_dst, bool advance, bool absolute, int B, int H,
+// advance: 0 = delta only, 1 = coords += delta and flow = coords (- x) (fc == 1), 2 = flow += delta (any fc)
+static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta_dst, int advance, bool absolute, int B, int H,
                    int W, hipStream_t s) {
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels, hxC = 2 * hid + ctx;
     const Lay lay = make_lay(H, W, true);
@@ -423,14 +428,14 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(256);
     const size_t lds = (size_t)(hid * 60 + fc * hid * 9 + 8 * fc * 32) * sizeof(float);
     NND_REQUIRE(hid % 8 == 0 && lds <= 64 * 1024, "flow_head.conv2: hidden_dim %d not supported", hid);
-    NND_REQUIRE(!advance || fc == 1, "flow_head.conv2: fused advance needs flow_channels == 1");
-    float* hx_flow = w.hx + (hxC - 1) * n;
+    NND_REQUIRE(advance != 1 || fc == 1, "flow_head.conv2: the coordinate advance needs flow_channels == 1");
+    float* hx_flow = w.hx + (hxC - fc) * n;
     if (fc == 1)
         hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance ? 1 : 0, absolute ? 1 : 0, lay);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance, absolute ? 1 : 0, lay);
     else
         hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, 0, 0, lay);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
     NND_LAUNCH_CHECK();
     return debug_sync("flow_head.conv2", s);
 }
@@ -485,7 +490,7 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
         NND_TRY(run_conv(p, blob, w, C_Q2, corr, nullptr, nullptr, B, H, W, s));
     }
     NND_TRY(run_conv(p, blob, w, C_FH1, corr, nullptr, nullptr, B, H, W, s));
-    NND_TRY(run_fc2(p, blob, w, delta_dst, false, false, B, H, W, s));
+    NND_TRY(run_fc2(p, blob, w, delta_dst, 0, false, B, H, W, s));
     if (mask_dst) {
         NND_TRY(run_conv(p, blob, w, C_M0, corr, nullptr, nullptr, B, H, W, s));
         NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
@@ -631,20 +636,39 @@ int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* pac
     return NND_OK;
 }
 
+// CREStereo variant of the loop (cre_stereo/model.py:221-284): the correlation features come from the AGCL kernels
+// (iter mode: extra == nullptr, needs the `warped` scratch; offset mode otherwise), the state is a 2-channel flow
+// and iteration `it` searches a 3x3 window when it is odd, 1x9 when even.
+struct CreArgs {
+    const float* f1;
+    const float* f2;
+    const float* extra;
+    float* warped;
+    int C;
+};
+
 // geo_pyramid != nullptr selects the IGEV variant: combined two-volume lookup over `groups` groups and
-// absolute coordinates into the update block / upsample (igev_stereo/model.py:152-158).
+// absolute coordinates into the update block / upsample (igev_stereo/model.py:152-158).  cre != nullptr selects the
+// CREStereo variant (then pyramid is unused and disp_init is the initial 2-channel flow, NCHW, or null for zero).
 static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
                           int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
                           int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W,
-                          int rate, int iters, void* stream, const float* geo_pyramid = nullptr, int groups = 1) {
+                          int rate, int iters, void* stream, const float* geo_pyramid = nullptr, int groups = 1,
+                          const CreArgs* cre = nullptr) {
     Plan p;
     int rc = make_plan(desc, &p);
     if (rc != NND_OK) return rc;
-    NND_REQUIRE(packed && pyramid && net && inp && up_out && workspace, "raft_stereo_refine: null pointer");
-    NND_REQUIRE(p.d.flow_channels == 1, "raft_stereo_refine: flow_channels must be 1");
+    NND_REQUIRE(packed && (pyramid || cre) && net && inp && up_out && workspace, "refine: null pointer");
     const bool igev = geo_pyramid != nullptr;
-    NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1) * (igev ? 2 * groups : 1),
-                "refine: cor_planes %d does not match levels*(2r+1)%s", p.d.cor_planes, igev ? "*2*groups" : "");
+    const int fc = p.d.flow_channels;
+    if (cre) {
+        NND_REQUIRE(fc == 2 && p.d.cor_planes == 36, "cre_stereo_refine: needs flow_channels 2 and cor_planes 36");
+        NND_REQUIRE(cre->f1 && cre->f2 && (cre->extra || cre->warped), "cre_stereo_refine: null feature map / scratch");
+    } else {
+        NND_REQUIRE(fc == 1, "raft_stereo_refine: flow_channels must be 1");
+        NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1) * (igev ? 2 * groups : 1),
+                    "refine: cor_planes %d does not match levels*(2r+1)%s", p.d.cor_planes, igev ? "*2*groups" : "");
+    }
 
     NND_REQUIRE(p.d.mask_channels == 9 * rate * rate, "raft_stereo_refine: mask_channels %d != 9*rate^2", p.d.mask_channels);
     NND_REQUIRE(B > 0 && H > 0 && W > 0 && iters > 0, "raft_stereo_refine: bad shape");
@@ -656,13 +680,27 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const int64_t n = lay.plane;  // channel stride of every (tile-major) workspace tensor
     NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s));
     NND_TRY(to_tiled(inp, w.hx + hid * n, hxC * n, B, ctx, H, W, s));
-    float* hx_flow = w.hx + (hxC - 1) * n;
+    float* hx_flow = w.hx + (hxC - fc) * n;
     const unsigned eg = (unsigned)cdiv64((int64_t)B * H * W, 256);
-    hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H, W,
-                       igev ? 1 : 0, lay);
-    NND_LAUNCH_CHECK();
+    if (cre) {
+        if (disp_init) {
+            NND_TRY(to_tiled(disp_init, w.flow, fc * n, B, fc, H, W, s));
+            NND_TRY(to_tiled(disp_init, hx_flow, hxC * n, B, fc, H, W, s));
+        } else {
+            NND_HIP_CHECK(hipMemsetAsync(w.flow, 0, sizeof(float) * B * fc * n, s));
+            for (int b = 0; b < B; ++b) NND_HIP_CHECK(hipMemsetAsync(hx_flow + b * hxC * n, 0, sizeof(float) * fc * n, s));
+        }
+    } else {
+        hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H,
+                           W, igev ? 1 : 0, lay);
+        NND_LAUNCH_CHECK();
+    }
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
-    auto lookup = [&](hipStream_t st_) -> int {
+    auto lookup = [&](hipStream_t st_, int it) -> int {
+        if (cre) {
+            if (cre->extra) return agcl_offset_launch(cre->f1, cre->f2, w.flow, cre->extra, w.corr, B, cre->C, H, W, it & 1, st_, true);
+            return agcl_iter_launch(cre->f1, cre->f2, w.flow, cre->warped, w.corr, B, cre->C, H, W, it & 1, st_, true);
+        }
         if (igev) return igev_lookup_launch(pyramid, geo_pyramid, w.coords, w.corr, B, groups, H, W, num_levels, radius, st_, true);
         return corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, st_, true);
     };
@@ -673,7 +711,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     Streams* st = single ? nullptr : side_streams();
     if (!st) {  // plain in-order version (also the debugging reference for the DAG below)
         for (int it = 0; it < iters; ++it) {
-            NND_TRY(lookup(s));
+            NND_REQUIRE(!cre, "cre_stereo_refine: NND_SINGLE_STREAM debugging path is RAFT/IGEV only");
+            NND_TRY(lookup(s, it));
             NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
             hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W,
                                igev ? 1 : 0, lay);
@@ -690,7 +729,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         // Hazards: mask.0 reads the h copy of parity it&1 (q2 of it+2 rewrites it only after advance(it+1), which
         // waited for up(it), and B runs mask.0(it) before up(it)); advance(it+1) rewrites flow only after up(it).
         static const bool no_fuse = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;
-        const bool fused_up = !no_fuse && mask_upsample_supported(rate, 2 * hid, 1);
+        const bool fused_up = !no_fuse && mask_upsample_supported(rate, 2 * hid, fc);
         NND_HIP_CHECK(hipEventRecord(st->adv, s));
         for (int it = 0; it < iters; ++it) {
             IoOpt opt;
@@ -698,10 +737,10 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             opt.advance = true;
             opt.absolute = igev;
             NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
-            NND_TRY(run_convf1(p, packed, w.flow, (int64_t)n, w.f1, B, H, W, st->a));
+            NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, st->a));
             NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
             NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
-            NND_TRY(lookup(s));
+            NND_TRY(lookup(s, it));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
             NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
@@ -718,20 +757,20 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, st->b));
             NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
             if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
-            NND_TRY(run_fc2(p, packed, w, w.delta, true, igev, B, H, W, s));
+            NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
             NND_HIP_CHECK(hipEventRecord(st->adv, s));
             NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
             if (fused_up)  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
                 NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow,
-                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, st->b, true));
+                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, st->b, true, fc));
             else
-                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, st->b, true));
+                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, fc, H, W, rate, st->b, true));
             NND_HIP_CHECK(hipEventRecord(st->up, st->b));
         }
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));   // join B
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));   // join A (already consumed, keeps the contract simple)
     }
-    if (low_out) NND_TRY(from_tiled(w.flow, n, low_out, B, 1, H, W, s));
+    if (low_out) NND_TRY(from_tiled(w.flow, fc * n, low_out, B, fc, H, W, s));
     if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
     return NND_OK;
 }
@@ -867,6 +906,19 @@ int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packe
     NND_REQUIRE(geo_pyramid && num_groups > 0, "igev_stereo_refine: geometry pyramid / groups missing");
     return enqueue_refine(desc, packed, feat_pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
                           net_out, workspace, B, H, W, rate, iters, stream, geo_pyramid, num_groups);
+}
+
+int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* fmap1, const float* fmap2,
+                          int C, const float* extra_offset, float* warped, const float* net, const float* inp,
+                          const float* flow_init, float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
+                          float* workspace, int B, int H, int W, int rate, int iters, void* stream) {
+    NND_REQUIRE(fmap1 && fmap2, "cre_stereo_refine: null feature map");
+    NND_REQUIRE(extra_offset || warped, "cre_stereo_refine: iter mode (extra_offset == NULL) needs the warped scratch");
+    int rc = agcl_check("cre_stereo_refine", B, C, H, W);
+    if (rc != NND_OK) return rc;
+    CreArgs cre{fmap1, fmap2, extra_offset, warped, C};
+    return enqueue_refine(desc, packed, nullptr, 0, 0, net, inp, flow_init, up_out, up_iter_stride, low_out, net_out, workspace,
+                          B, H, W, rate, iters, stream, nullptr, 1, &cre);
 }
 
 int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const float* flow, float* out, int B, int Cin, int H,

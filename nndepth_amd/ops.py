@@ -242,6 +242,37 @@ class UpdateBlockEngine:
                                              _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "igev_stereo_refine")
         return up, low, net_out
 
+    def refine_cre(self, fmap1, fmap2, net, inp, rate: int, iters: int, flow_init=None, extra_offset=None,
+                   scratch=None, keep_all: bool = True):
+        """One CREStereo cascade stage (AGCL -> update block -> flow += delta -> 2-channel upsample, `iters` times)
+        -> (up (iters or 1, B,2,rate*H,rate*W), flow (B,2,H,W), net).  extra_offset=None: iter mode."""
+        if self.packed is None:
+            raise NndError("UpdateBlockEngine: parameters not loaded")
+        d = _dev(fmap1, fmap2, net, inp, self.packed)
+        fmap1, fmap2, net, inp = (t.contiguous() for t in (fmap1, fmap2, net, inp))
+        B, Cf, H, W = fmap1.shape
+        if fmap2.shape != fmap1.shape or tuple(net.shape[2:]) != (H, W):
+            raise NndError(f"refine_cre: shapes fmap {tuple(fmap1.shape)} / {tuple(fmap2.shape)}, net {tuple(net.shape)}")
+        n_up = iters if keep_all else 1
+        up = torch.empty((n_up, B, 2, rate * H, rate * W), dtype=torch.float32, device=d)
+        low = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)
+        net_out = torch.empty_like(net)
+        ws = self.workspace(B, H, W, d)
+        stride = up[0].numel() if keep_all else 0
+        if flow_init is not None:
+            flow_init = flow_init.contiguous()
+            _dev(flow_init)
+        if extra_offset is not None:
+            extra_offset = extra_offset.contiguous()
+            _dev(extra_offset)
+        elif scratch is None or scratch.numel() < fmap2.numel():
+            scratch = torch.empty_like(fmap2)
+        with torch.cuda.device(d):
+            check(lib.nnd_cre_stereo_refine(C.byref(self.desc), _p(self.packed), _p(fmap1), _p(fmap2), Cf, _p(extra_offset),
+                                            _p(scratch), _p(net), _p(inp), _p(flow_init), _p(up), stride, _p(low),
+                                            _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "cre_stereo_refine")
+        return up, low, net_out
+
     # ---- profiling (bench.py roofline)
     def conv_names(self) -> List[str]:
         n = lib.nnd_num_convs(C.byref(self.desc))

@@ -479,3 +479,21 @@ def test_cre_cascade_small_golden(gold, cre_sd):
     assert len(outs) == 2 and max(errs) <= 1e-4
     m.test_mode = True
     assert torch.equal(m(fr1.to(DEV), fr2.to(DEV), flow_init=t(g["flow_init"]).to(DEV)), outs[-1]["up_disp"])
+
+
+def test_cre_fused_stage_matches_seam_by_seam(cre_sd):
+    """nnd_cre_stereo_refine (one call per cascade stage, context terms precomputed, fused mask+upsample, 3 streams)
+    against the seam-by-seam loop over the same kernels: all 8 outputs of a small cascade."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cre_stereo import CREStereoBase
+    fr1, fr2 = weightgen.synthetic_frames(4, 1, 160, 224)
+    m = CREStereoBase(iters=4)
+    m.load_state_dict(cre_sd, strict=True)
+    m = m.to(DEV).eval()
+    fused = m(fr1.to(DEV), fr2.to(DEV))
+    m.fused_loop = False
+    seam = m(fr1.to(DEV), fr2.to(DEV))
+    assert len(fused) == len(seam) == 8
+    errs = [(a["up_disp"] - b["up_disp"]).abs().max().item() for a, b in zip(fused, seam)]
+    print("\ncre fused vs seam-by-seam:", " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) <= 5e-5
