@@ -228,34 +228,46 @@ __global__ void from_tiled_kernel(const float* __restrict__ src, long sbs, float
 // recurrence update of nndepth/models/raft_stereo/model.py:134-135 is fused in: coords += delta; flow = coords - x
 // (or the coordinate itself for IGEV, `absolute`), mirrored into the GRU input buffer.
 template <int FC>
-__global__ void __launch_bounds__(256) flow_head2_kernel(const float* __restrict__ x, long xbs, int hid, const float* __restrict__ w,
+__global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict__ x, long xbs, int hid, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ delta,
                                                          float* __restrict__ coords, float* __restrict__ flow,
                                                          float* __restrict__ hx_flow, long hx_bs, int H, int W, int tiles_x,
                                                          int advance, int absolute, Lay lay) {
+    // One 4x8 pixel tile per workgroup, 512 threads.  Staging: thread = (patch position, channel group of 8), its
+    // loads are independent and issued back to back (clamped addresses, zero-filled by select).  Compute: thread =
+    // (pixel, slice of hid/16 channels); the 16 partial sums per pixel meet in LDS.
     extern __shared__ float sm[];
-    float* patch = sm;                 // [hid][60]
-    float* wl = sm + hid * 60;         // [FC][hid][9]
-    float* part = wl + FC * hid * 9;   // [8][FC][32]
+    float* patch = sm;                  // [hid][64] (60 used)
+    float* wl = sm + hid * 64;          // [FC][hid][9]
+    float* part = wl + FC * hid * 9;    // [16][FC][32]
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
     const long HW = lay.plane;
     const float* src = x + b * xbs;
-    for (int e = tid; e < hid * 60; e += 256) {
-        const int ci = e / 60, pos = e % 60;
+    {
+        const int pos = tid & 63, cg = tid >> 6;  // 8 channel groups
         const int gy = ty0 + pos / 10 - 1, gx = tx0 + pos % 10 - 1;
-        patch[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[ci * HW + pix_off(lay, gy, gx)] : 0.f;
+        const bool ok = pos < 60 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const long off = ok ? pix_off(lay, gy, gx) : 0;
+        for (int c0 = cg; c0 < hid; c0 += 64) {  // 8 loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(long)min(c0 + 8 * j, hid - 1) * HW + off];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + 8 * j < hid) patch[(c0 + 8 * j) * 64 + pos] = ok ? v[j] : 0.f;
+        }
     }
-    for (int e = tid; e < FC * hid * 9; e += 256) wl[e] = w[e];
+    for (int e = tid; e < FC * hid * 9; e += 512) wl[e] = w[e];
     __syncthreads();
-    const int px = tid & 31, slice = tid >> 5;
+    const int px = tid & 31, slice = tid >> 5;  // 16 slices
     const int r = px >> 3, c = px & 7;
-    const int cps = hid / 8;
+    const int cps = hid / 16;
     float acc[FC];
 #pragma unroll
     for (int f = 0; f < FC; ++f) acc[f] = 0.f;
     for (int ci = slice * cps; ci < (slice + 1) * cps; ++ci) {
-        const float* pp = patch + ci * 60 + r * 10 + c;
+        const float* pp = patch + ci * 64 + r * 10 + c;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float v = pp[(t / 3) * 10 + t % 3];
@@ -270,7 +282,7 @@ __global__ void __launch_bounds__(256) flow_head2_kernel(const float* __restrict
         const int f = tid >> 5, p2 = tid & 31;
         float sum = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) sum += part[(sl * FC + f) * 32 + p2];
+        for (int sl = 0; sl < 16; ++sl) sum += part[(sl * FC + f) * 32 + p2];
         sum += bias[f];
         const int y = ty0 + (p2 >> 3), xx = tx0 + (p2 & 7);
         if (y < H && xx < W) {
@@ -425,9 +437,9 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     const Lay lay = make_lay(H, W, true);
     const int64_t n = lay.plane;
     const int tiles_x = cdiv(W, 8);
-    dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(256);
-    const size_t lds = (size_t)(hid * 60 + fc * hid * 9 + 8 * fc * 32) * sizeof(float);
-    NND_REQUIRE(hid % 8 == 0 && lds <= 64 * 1024, "flow_head.conv2: hidden_dim %d not supported", hid);
+    dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(512);
+    const size_t lds = (size_t)(hid * 64 + fc * hid * 9 + 16 * fc * 32) * sizeof(float);
+    NND_REQUIRE(hid % 16 == 0 && lds <= 64 * 1024, "flow_head.conv2: hidden_dim %d not supported", hid);
     NND_REQUIRE(advance != 1 || fc == 1, "flow_head.conv2: the coordinate advance needs flow_channels == 1");
     float* hx_flow = w.hx + (hxC - fc) * n;
     if (fc == 1)
@@ -720,30 +732,33 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s, true));
         }
     } else {
-        // Per-iteration DAG over three streams (M = caller's stream carries the recurrence):
-        //   M: lookup, convc1, convc2, [f2] conv, zr1, q1, zr2, q2 (+h copy) ->(q2) flow_head.conv1, [up] conv2+advance ->(adv)
+        // Per-iteration DAG over two streams (M = caller's stream carries the recurrence):
+        //   M: lookup, convc1, convc2, [f2] conv, zr1, q1, zr2, q2, flow_head.conv1, flow_head.conv2+advance ->(adv),
+        //      mask.0, mask.2 + convex upsample (fused)
         //   A: (adv) convf1, convf2 ->(f2)                              flow branch of the motion encoder
-        //   B: (q2) mask.0, (adv) mask.2 + convex upsample ->(up)        output-only work, overlaps iteration i+1
-        // (forking mask.0 from `adv` instead of `q2` saves one event record on M but measured 4 % slower: mask.0 then
-        //  competes with convc2 instead of filling the bubbles of flow_head.conv1/conv2.)
-        // Hazards: mask.0 reads the h copy of parity it&1 (q2 of it+2 rewrites it only after advance(it+1), which
-        // waited for up(it), and B runs mask.0(it) before up(it)); advance(it+1) rewrites flow only after up(it).
+        // Measured on MI355X at 544x960 (ms per pair): M+A 17.17 | M+A+B (mask branch on a third stream, needs a
+        // double-buffered copy of h and 3 more event operations on M per iteration) 17.97 | everything on M 17.68 |
+        // M only, captured into a hipGraph 17.64.  The kernels of one iteration already fill the chip (the sum of the
+        // stand-alone kernel times equals the in-loop time), so a third stream buys no overlap and each event
+        // record / wait on M costs a ~7 us bubble.  NND_STREAM_B=1 / NND_NO_STREAM_A=1 select the other schedules.
         static const bool no_fuse = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;
         const bool fused_up = !no_fuse && mask_upsample_supported(rate, 2 * hid, fc);
         NND_HIP_CHECK(hipEventRecord(st->adv, s));
         for (int it = 0; it < iters; ++it) {
             IoOpt opt;
-            opt.parity = it & 1;
+            opt.parity = getenv("NND_STREAM_B") ? (it & 1) : -1;  // the h copy is only needed when mask.0 runs on stream B
             opt.advance = true;
             opt.absolute = igev;
-            NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
-            NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, st->a));
-            NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
-            NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
+            static const bool no_a = getenv("NND_NO_STREAM_A") != nullptr;  // measured: flow branch on M instead of A is 2.6 % slower
+            hipStream_t sa = no_a ? s : st->a;
+            if (!no_a) NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
+            NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, sa));
+            NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, sa));
+            if (!no_a) NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
             NND_TRY(lookup(s, it));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
-            NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
+            if (!no_a) NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
             NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_ZR1X, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_Q1X, c, nullptr, nullptr, B, H, W, s, opt));
@@ -751,24 +766,33 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
                 NND_TRY(run_conv(p, packed, w, C_ZR2X, c, nullptr, nullptr, B, H, W, s));
                 NND_TRY(run_conv(p, packed, w, C_Q2X, c, nullptr, nullptr, B, H, W, s, opt));
             }
-            NND_HIP_CHECK(hipEventRecord(st->q2, s));
-            NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->q2, 0));
-            NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, st->b, opt));
-            if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, st->b));
+            static const bool no_b = getenv("NND_STREAM_B") == nullptr;  // default: output branch on the main stream (see above)
+            hipStream_t sb = no_b ? s : st->b;
+            if (!no_b) {
+                NND_HIP_CHECK(hipEventRecord(st->q2, s));
+                NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->q2, 0));
+                NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, sb, opt));
+                if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, sb));
+            }
             NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
-            if (it > 0) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
+            if (it > 0 && !no_b) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
             NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
-            NND_HIP_CHECK(hipEventRecord(st->adv, s));
-            NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
+            NND_HIP_CHECK(hipEventRecord(st->adv, s));  // the flow is final: stream A may start the next flow branch
+            if (no_b) {
+                NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, sb, opt));
+                if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, sb));
+            } else {
+                NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
+            }
             if (fused_up)  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
                 NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow,
-                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, st->b, true, fc));
+                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, sb, true, fc));
             else
-                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, fc, H, W, rate, st->b, true));
-            NND_HIP_CHECK(hipEventRecord(st->up, st->b));
+                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, fc, H, W, rate, sb, true));
+            if (!no_b) NND_HIP_CHECK(hipEventRecord(st->up, st->b));
         }
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));   // join B
-        NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));   // join A (already consumed, keeps the contract simple)
+        if (!getenv("NND_NO_STREAM_A")) NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));   // join A (already consumed, keeps the contract simple)
     }
     if (low_out) NND_TRY(from_tiled(w.flow, fc * n, low_out, B, fc, H, W, s));
     if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
