@@ -153,6 +153,42 @@ int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin,
 int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
                        int Cout, int KH, int KW, int relu, void* stream);
 
+/* Convolution + folded eval-mode BatchNorm + ReLU / residual epilogue (the building block of the encoder):
+ *   y = conv(x; w, stride, "same" padding K/2) ; y = (y + bias - mean) * gamma / sqrt(var + eps) + beta   [norm optional]
+ *   if relu: y = max(y, 0);  if residual: y = residual + y;  if relu_after_residual: y = max(y, 0)
+ * Stands in for nn.Conv2d [+ nn.BatchNorm2d(eval)] [+ ReLU] and the `relu(x + y)` of
+ * nndepth/blocks/residual_block.py:53-60.  Kernels 1x1 / 3x3 at stride 1 or 2 (1x5 / 5x1 at stride 1);
+ * x (B,Cin,Hin,Win) -> y (B,Cout,ceil(Hin/stride),ceil(Win/stride)), residual like y.  nnd_conv_pack is a HOST function
+ * (the norm is folded in double precision into a per-channel scale / shift); bn_* may be NULL (no norm).          */
+typedef struct nnd_conv_desc {
+    int Cout, Cin, KH, KW, stride;
+} nnd_conv_desc;
+int64_t nnd_conv_packed_floats(const nnd_conv_desc* desc);
+int nnd_conv_pack(const nnd_conv_desc* desc, const float* w_host, const float* bias_host, const float* bn_gamma,
+                  const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, float* packed_host);
+int nnd_conv_forward(const nnd_conv_desc* desc, const float* packed_dev, const float* x, const float* residual, float* y,
+                     int B, int Hin, int Win, int relu, int relu_after_residual, void* stream);
+
+/* ------------------------------------------------------------------------- feature encoder
+ * Replaces BasicEncoder.forward  nndepth/encoders/basic_encoder.py:71-93 (norm_fn "batch" in eval mode, or "none"),
+ * ResidualBlock.forward nndepth/blocks/residual_block.py:53-60 and, optionally, the context projection
+ * `cnet_proj` of nndepth/models/raft_stereo/model.py:53-55 applied to the first n_cnet maps (the left frames).
+ * norm: 0 = none, 1 = BatchNorm2d (running statistics).  cnet_dim: output channels of cnet_proj, 0 = absent.
+ * nnd_encoder_pack (HOST): `tensors` = units of 6 pointers {weight, bias, norm weight, norm bias, running_mean,
+ * running_var} (the last four NULL where there is no norm) in the order: conv1 | for each residual block layer1.0,
+ * layer1.1, layer2.0, layer2.1, layer3.0, layer3.1: conv1, conv2, downsample.0 (its norm = norm3) | conv2 | cnet_proj.0.
+ * nnd_encoder_forward: frames (N,3,H,W) -> fmap (N,output_dim,H/8,W/8); cnet_out (n_cnet,cnet_dim,H/8,W/8) or NULL.
+ * workspace: nnd_encoder_workspace_floats(desc, N, H, W) floats, caller-owned.                                     */
+typedef struct nnd_encoder_desc {
+    int output_dim, norm, cnet_dim;
+} nnd_encoder_desc;
+int nnd_encoder_num_tensors(const nnd_encoder_desc* desc);
+int64_t nnd_encoder_packed_floats(const nnd_encoder_desc* desc);
+int64_t nnd_encoder_workspace_floats(const nnd_encoder_desc* desc, int N, int H, int W);
+int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* tensors_host, float bn_eps, float* packed_host);
+int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed_dev, const float* frames, float* fmap,
+                        float* cnet_out, int n_cnet, float* workspace, int N, int H, int W, void* stream);
+
 /* Fused tail of the mask head + convex upsample (the (B, 9*rate^2, H, W) mask is never written):
  *   out = convex_upsample(flow, 0.25 * conv1x1(x; W, b))      x (B,Cin,H,W), flow (B,1,H,W), out (B,1,rate*H,rate*W)
  * Replaces update_block.py:97-101,111 (mask.2, x0.25) + raft_stereo/model.py:93-105.  `packed_dev` is the blob of

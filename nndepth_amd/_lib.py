@@ -19,6 +19,14 @@ class UpdateBlockDesc(C.Structure):
                 ("flow_channels", C.c_int32), ("mask_channels", C.c_int32), ("gru_kind", C.c_int32)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32)]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("output_dim", C.c_int32), ("norm", C.c_int32), ("cnet_dim", C.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/nndepth_amd.h one to one
 _P = C.c_void_p
 _I = C.c_int
@@ -51,6 +59,14 @@ SIGNATURES = {
                                     _I, _I, _I, _I, _I, _P]),
     "nnd_cre_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                    _I, _I, _I, _I, _I, _P]),
+    "nnd_conv_packed_floats": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "nnd_conv_pack": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P]),
+    "nnd_conv_forward": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_encoder_num_tensors": (_I, [C.POINTER(EncoderDesc)]),
+    "nnd_encoder_packed_floats": (C.c_int64, [C.POINTER(EncoderDesc)]),
+    "nnd_encoder_workspace_floats": (C.c_int64, [C.POINTER(EncoderDesc), _I, _I, _I]),
+    "nnd_encoder_pack": (_I, [C.POINTER(EncoderDesc), C.POINTER(_P), C.c_float, _P]),
+    "nnd_encoder_forward": (_I, [C.POINTER(EncoderDesc), _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
                               C.POINTER(C.c_double)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),

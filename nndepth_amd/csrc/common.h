@@ -47,12 +47,16 @@ enum ConvEpilogue {
     EPI_GRU_ZR = 2,  // co <  hidden: out0[co] = sigmoid(v)                (z)
                      // co >= hidden: out1[co-hidden] = sigmoid(v) * aux0  (r*h)
     EPI_GRU_Q = 3,   // q = tanh(v); out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z); out1 (optional) = copy
-    EPI_SCALE = 4    // out0 = scale * v
+    EPI_SCALE = 4,   // out0 = scale * v
+    EPI_AFFINE = 5   // y = acc * cscale[co] + shift[co] (folded norm; shift in the bias slot); flags bit 0: ReLU;
+                     // aux0 (optional): y = aux0 + y; flags bit 1: ReLU          (encoder / residual blocks)
 };
 
 // One convolution layer inside a packed parameter blob.
 struct ConvLayer {
-    int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (32, or 128 for wide 1x1)
+    int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (32, 128 for wide 1x1, 16 for stride 2)
+    int stride = 1;               // 1 or 2 ("same" padding K/2; output = ceil(input / stride) for odd K)
+    int64_t s_off = -1;           // float offset of the per-channel scale (EPI_AFFINE), ncb*32 floats; -1: none
     int nchunks;                  // ceil(Cin / CI_T)
     int ncb;                      // ceil(Cout / 32) output-channel blocks
     int64_t w_off, b_off;         // float offsets in the blob
@@ -75,12 +79,14 @@ struct ConvIO {
     Act bmap;            // optional per-pixel bias map (replaces the per-channel bias)
     int hidden = 0;
     float scale = 1.f;
+    int Hin = 0, Win = 0;  // input size when it differs from the output size (stride 2); 0: same
+    int flags = 0;         // EPI_AFFINE flags
     bool src_tiled = false;  // layout.h: sources are tile-major (internal workspace) instead of NCHW
     bool dst_tiled = false;  // ... out0/out1/aux0/aux1/bmap
 };
 
 // input channels per K-chunk for a layer shape (host packer and kernels must agree)
-int conv_ci_t(int KH, int KW, int Cin);
+int conv_ci_t(int KH, int KW, int Cin, int stride = 1);
 
 int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi,
                 int B, int H, int W, hipStream_t stream);

@@ -79,8 +79,11 @@ struct ConvArgs {
     const float* bmap;  // optional per-pixel bias (B, Cout, H, W) added instead of bias[co]
     long bmbs;
     Lay ls, ld;         // layout of the sources / of every destination-side tensor (out*, aux*, bmap)
-    int H, W, Cout, nchunks, epi, hidden;
+    int H, W, Cout, nchunks, epi, hidden;  // H, W: OUTPUT size
+    int Hin, Win;                          // input size (== H, W for stride 1)
     int tiles_x, wco, ks, npos, ngroups;
+    int flags;                             // EPI_AFFINE: bit 0 ReLU after the affine, bit 1 ReLU after the residual add
+    const float* cscale;                   // EPI_AFFINE: per-channel scale (folded norm), shift comes in through `bias`
     float scale;
 };
 
@@ -110,7 +113,7 @@ __device__ __forceinline__ float tanhf_(float v) {
 }
 
 // NE: patch elements staged per thread per super-chunk (the thread owns one patch position and NE channels)
-template <int KH, int KW, int CI_T, int P, int NE>
+template <int KH, int KW, int CI_T, int P, int NE, int STR = 1>
 __global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArgs a) {
     constexpr int NT = KH * KW;
     constexpr int SG = CI_T < 32 ? CI_T : 32;  // channels per pipeline step
@@ -134,12 +137,15 @@ __global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArg
     const int cb = blockIdx.y * wco + cbi;
     const bool active = cb * 32 < a.Cout;  // trailing waves of the last workgroup only help staging
     const int b = blockIdx.z;
-    const int H = a.H, W = a.W;
+    const int H = a.H, W = a.W, Hin = a.Hin, Win = a.Win;
     const long SP = a.ls.plane, DP = a.ld.plane;  // channel strides of the source / destination tensors
     // LDS patch geometry is compile-time so every B-operand read is base + immediate offset.
     // Row stride S is an odd multiple of SC: lanes (r, c) then hit 32 distinct banks.
-    constexpr int PR = SR + KH - 1, PC = P * SC + KW - 1;
-    constexpr int S = patch_stride(PC, SC), PATCH = PR * S;
+    // Stride 2: the input patch is stored split into its 4 (row, col) parity phases, so that the operand of tap
+    // (dy, dx) for output pixel (r, c) — input (2r+dy, 2c+dx) — is again lane_base + an immediate, with unit lane stride.
+    constexpr int PR = (SR - 1) * STR + KH, PC = (P * SC - 1) * STR + KW;
+    constexpr int PRH = (PR + STR - 1) / STR, PCH = (PC + STR - 1) / STR;  // rows / cols of one phase (== PR, PC for stride 1)
+    constexpr int S = patch_stride(PCH, SC), PHASE = PRH * S, PATCH = STR * STR * PHASE;
     const int SCH = ks * CI_T;  // channels per super-chunk
 
     // ---- staging role of this thread: patch position `pos`, channels cg, cg+ngroups, ... (NE of them)
@@ -147,10 +153,10 @@ __global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArg
     const int pos = tid % npos, cg = tid / npos;
     const bool stager = cg < ngroups;
     const int pr = pos / PC, pc = pos - pr * PC;
-    const int gy = ty0 + pr - PH, gx = tx0 + pc - PW;
-    const bool inimg = stager && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int gy = ty0 * STR + pr - PH, gx = tx0 * STR + pc - PW;
+    const bool inimg = stager && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
     const int goff0 = inimg ? (int)pix_off(a.ls, gy, gx) : 0;
-    const int loff0 = pr * S + pc;
+    const int loff0 = ((pr % STR) * STR + (pc % STR)) * PHASE + (pr / STR) * S + pc / STR;
     const int trash = 2 * SCH * PATCH;  // one spare LDS word swallows the stores of non-staging threads
 
     f32x16 acc[P];
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArg
 #pragma unroll
             for (int i = g * 8; i < g * 8 + 8; ++i) {
                 const int pair = i / P, pp = i % P;
-                dst[i] = xb[(grp * SG + pair * 2) * PATCH + dy * S + dx + pp * SC];
+                dst[i] = xb[(grp * SG + pair * 2) * PATCH + ((dy % STR) * STR + dx % STR) * PHASE + (dy / STR) * S + dx / STR + pp * SC];
             }
         };
         constexpr int NRG = NB / 8;  // read groups per step
@@ -360,6 +366,15 @@ __global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArg
                 bias_r[reg] = ok ? a.bmap[b * a.bmbs + co * DP + pix] : 0.f;
             }
         }
+        if (epi == EPI_AFFINE) {  // z_r <- per-channel scale, h_r <- residual (dst layout), bias_r = shift
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
+                z_r[reg] = ok ? a.cscale[co] : 0.f;
+                h_r[reg] = (ok && a.aux0) ? a.aux0[b * a.abs0 + co * DP + pix] : 0.f;
+            }
+        }
         if (epi == EPI_GRU_ZR || epi == EPI_GRU_Q) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -390,6 +405,12 @@ __global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArg
                 a.out0[b * a.obs0 + co * DP + pix] = v;
             } else if (epi == EPI_SCALE) {
                 a.out0[b * a.obs0 + co * DP + pix] = a.scale * v;
+            } else if (epi == EPI_AFFINE) {  // folded norm: y = acc*scale + shift; optional ReLU, residual add, ReLU
+                float y2 = fmaf(acc[pp][reg], z_r[reg], bias_r[reg]);
+                if (a.flags & 1) y2 = fmaxf(y2, 0.f);
+                if (a.aux0) y2 = h_r[reg] + y2;
+                if (a.flags & 2) y2 = fmaxf(y2, 0.f);
+                a.out0[b * a.obs0 + co * DP + pix] = y2;
             } else if (epi == EPI_GRU_ZR) {
                 const float sg = sigmoidf_(v);
                 if (co < a.hidden) a.out0[b * a.obs0 + co * DP + pix] = sg;
@@ -437,14 +458,17 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
                 if (P == 2 && wco * ks > 8) continue;
                 const int SC = NND_SC, SR = 32 / NND_SC;
                 int tx = cdiv(W, P * SC), ty = cdiv(H, SR);
-                int PR = SR + L.KH - 1, PC = P * SC + L.KW - 1;
-                int S = patch_stride(PC, SC);
+                const int st = L.stride;
+                if (st == 2 && P != 1) continue;  // stride-2 kernels are instantiated for P = 1 only
+                int PR = (SR - 1) * st + L.KH, PC = (P * SC - 1) * st + L.KW;
+                int PRH = (PR + st - 1) / st, PCH = (PC + st - 1) / st;
+                int S = patch_stride(PCH, SC);
                 int npos = PR * PC;
                 if (npos > nthreads) continue;
                 int ngroups = nthreads / npos;
                 int ne = cdiv(ks * L.CI_T, ngroups);
                 if (ne > 16) continue;
-                size_t lds = ((size_t)2 * ks * L.CI_T * PR * S + 1) * sizeof(float);
+                size_t lds = ((size_t)2 * ks * L.CI_T * st * st * PRH * S + 1) * sizeof(float);
                 size_t red = ks > 1 ? (size_t)wco * ks * P * 1024 * sizeof(float) : 0;
                 if (red > lds) lds = red;
                 if (lds > 160 * 1024) continue;
@@ -472,9 +496,9 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
     return found;
 }
 
-template <int KH, int KW, int CI_T, int P, int NE>
+template <int KH, int KW, int CI_T, int P, int NE, int STR = 1>
 static int launch_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    auto kern = conv_mfma_kernel<KH, KW, CI_T, P, NE>;
+    auto kern = conv_mfma_kernel<KH, KW, CI_T, P, NE, STR>;
     if (lds > 64 * 1024) {
         static bool raised = false;  // per instantiation; idempotent, so a benign race at worst
         if (!raised) {
@@ -500,7 +524,11 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
                 hipStream_t stream) {
     NND_REQUIRE(io.src0.C + io.src1.C == L.Cin, "conv: source channels %d+%d != Cin %d", io.src0.C, io.src1.C, L.Cin);
     NND_REQUIRE(io.src1.C == 0 || io.src0.C % L.CI_T == 0, "conv: first source (%d ch) must be a multiple of %d", io.src0.C, L.CI_T);
-    NND_REQUIRE((long)(L.Cin + 2 * L.CI_T) * tiled_plane(H, W) < (1L << 31), "conv: plane offsets exceed 32 bits");
+    const int Hin = io.Hin > 0 ? io.Hin : H, Win = io.Win > 0 ? io.Win : W;
+    NND_REQUIRE(L.stride == 1 || L.stride == 2, "conv: stride %d not supported", L.stride);
+    NND_REQUIRE(H == (Hin + L.stride - 1) / L.stride && W == (Win + L.stride - 1) / L.stride,
+                "conv: output %dx%d does not match input %dx%d at stride %d", H, W, Hin, Win, L.stride);
+    NND_REQUIRE((long)(L.Cin + 2 * L.CI_T) * tiled_plane(Hin, Win) < (1L << 31), "conv: plane offsets exceed 32 bits");
     TileCfg cfg;
     NND_REQUIRE(pick_tile(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv: no tile configuration for %dx%d Cin=%d", L.KH, L.KW, L.Cin);
     ConvArgs a;
@@ -514,9 +542,12 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
-    a.ls = make_lay(H, W, io.src_tiled);
+    a.ls = make_lay(Hin, Win, io.src_tiled);
     a.ld = make_lay(H, W, io.dst_tiled);
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
+    a.Hin = Hin; a.Win = Win; a.flags = io.flags;
+    a.cscale = L.s_off >= 0 ? blob + L.s_off : nullptr;
+    NND_REQUIRE(epi != EPI_AFFINE || a.cscale, "conv: EPI_AFFINE needs a packed scale vector");
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks;
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;
     a.scale = io.scale;
@@ -526,6 +557,11 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
         fprintf(stderr, "[nnd] conv %dx%d Cin=%d Cout=%d CI_T=%d: P=%d, wco=%d, ks=%d, ne=%d, grid %ux%ux%u, lds %zu B\n",
                 L.KH, L.KW, L.Cin, L.Cout, L.CI_T, cfg.P, cfg.wco, cfg.ks, cfg.ne, grid.x, grid.y, grid.z, cfg.lds);
     int rc = NND_ERR_UNSUPPORTED;
+    if (L.stride == 2) {
+        if (L.KH == 3 && L.KW == 3 && L.CI_T == 16) rc = launch_one<3, 3, 16, 1, 16, 2>(a, grid, block, cfg.lds, stream);
+        else if (L.KH == 1 && L.KW == 1 && L.CI_T == 16) rc = launch_one<1, 1, 16, 1, 16, 2>(a, grid, block, cfg.lds, stream);
+        else set_error("conv %dx%d stride 2 CI_T=%d not instantiated", L.KH, L.KW, L.CI_T);
+    } else
     if (L.KH == 1 && L.KW == 1 && L.CI_T == 128) rc = launch_shape<1, 1, 128>(a, cfg, grid, block, stream);
     else if (L.KH == 1 && L.KW == 1 && L.CI_T == 32) rc = launch_shape<1, 1, 32>(a, cfg, grid, block, stream);
     else if (L.KH == 3 && L.KW == 3 && L.CI_T == 32) rc = launch_shape<3, 3, 32>(a, cfg, grid, block, stream);
@@ -538,7 +574,10 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
 }
 
 // input channels per K-chunk for a layer shape (the host packer and the kernels must agree)
-int conv_ci_t(int KH, int KW, int Cin) { return (KH == 1 && KW == 1 && Cin >= 128) ? 128 : 32; }
+int conv_ci_t(int KH, int KW, int Cin, int stride) {
+    if (stride == 2) return 16;  // the phase-split stride-2 patch is 4x larger per channel
+    return (KH == 1 && KW == 1 && Cin >= 128) ? 128 : 32;
+}
 
 // The packed layer may take only a subset of the source tensor's input channels: packed channel ci reads source
 // channel ci_map[ci] of a (cout, cin_src, KH, KW) tensor (ci_map == nullptr: identity, cin_src = L.Cin).

@@ -1,0 +1,349 @@
+// Feature encoder of RAFT-Stereo on the MFMA convolution (the row next to the refinement loop).
+//
+// Replaces nndepth/encoders/basic_encoder.py:71-93 (BasicEncoder, norm_fn = "batch" in eval mode or "none"),
+// nndepth/blocks/residual_block.py:53-60 (ResidualBlock: the 1x1 projection shortcut is ALWAYS applied, Q3) and the
+// cnet_proj conv of nndepth/models/raft_stereo/model.py:53-55 (reference; restated in oracle/torch_ref.py:
+// basic_encoder / residual_block).
+//
+//   conv1 7x7 s2 (3 -> 64) + norm + ReLU            stem_kernel (VALU: Cin = 3 is too shallow for the MFMA path)
+//   6 residual blocks                                conv_mfma, 3 launches per block:
+//       y  = ReLU(norm1(conv1 3x3 (stride s)(x)))        EPI_AFFINE | relu
+//       sc = norm3(conv 1x1 (stride s)(x))               EPI_AFFINE
+//       x' = ReLU(sc + ReLU(norm2(conv2 3x3(y))))        EPI_AFFINE | relu | residual | relu
+//   conv2 1x1 (128 -> output_dim)                    conv_mfma, writes the NCHW result
+//   cnet_proj 3x3 (output_dim -> ctx + hid) + ReLU   conv_mfma on the first half of the batch (the left frames)
+//
+// Eval-mode BatchNorm is folded at pack time (host, double precision) into a per-channel scale and shift applied in the
+// conv epilogue: y = acc * (gamma / sqrt(var + eps)) + ((bias - mean) * gamma / sqrt(var + eps) + beta).
+// Intermediate activations live in the tile-major workspace layout (layout.h); the input frames and the outputs are NCHW.
+#include "common.h"
+#include "layout.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace nnd {
+
+// ------------------------------------------------------------------------------------------ generic conv + norm
+static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total) {
+    NND_REQUIRE(d, "conv: null descriptor");
+    NND_REQUIRE(d->Cout > 0 && d->Cin > 0, "conv: bad channel counts");
+    NND_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d not supported (1, 2)", d->stride);
+    const bool k11 = d->KH == 1 && d->KW == 1, k33 = d->KH == 3 && d->KW == 3;
+    if (d->stride == 2)
+        NND_REQUIRE(k11 || k33, "conv: stride 2 is built for 1x1 and 3x3 kernels");
+    else
+        NND_REQUIRE(k11 || k33 || (d->KH == 1 && d->KW == 5) || (d->KH == 5 && d->KW == 1),
+                    "conv: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", d->KH, d->KW);
+    ConvLayer l;
+    l.KH = d->KH; l.KW = d->KW; l.Cin = d->Cin; l.Cout = d->Cout; l.stride = d->stride;
+    l.CI_T = conv_ci_t(d->KH, d->KW, d->Cin, d->stride);
+    l.nchunks = cdiv(d->Cin, l.CI_T);
+    l.ncb = cdiv(d->Cout, 32);
+    int64_t off = 0;
+    l.w_off = off; off += l.w_floats();
+    l.b_off = off; off += l.b_floats();
+    l.s_off = off; off += l.b_floats();
+    *L = l;
+    if (total) *total = off;
+    return NND_OK;
+}
+
+// packs `w` (Cout,Cin,KH,KW) / bias and the folded norm into blob + base (layer offsets are relative to base)
+static void pack_conv_norm(const ConvLayer& L, const float* w, const float* bias, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, float* base) {
+    const float* ws[1] = {w};
+    const float* bs[1] = {nullptr};
+    int co[1] = {L.Cout};
+    pack_conv(L, 1, ws, bs, co, base);
+    float* shift = base + L.b_off;
+    float* scale = base + L.s_off;
+    for (int c = 0; c < L.ncb * 32; ++c) {
+        double sc = 1.0, sh = 0.0;
+        if (c < L.Cout) {
+            const double b = bias ? (double)bias[c] : 0.0;
+            if (gamma) {
+                sc = (double)gamma[c] / std::sqrt((double)var[c] + (double)eps);
+                sh = (b - (double)mean[c]) * sc + (double)beta[c];
+            } else {
+                sh = b;
+            }
+        }
+        scale[c] = (float)sc;
+        shift[c] = (float)sh;
+    }
+}
+
+static int run_conv_norm(const ConvLayer& L, const float* base, const float* x, int64_t xbs, bool x_tiled, const float* res,
+                         int64_t rbs, float* y, int64_t ybs, bool y_tiled, int flags, int B, int Hin, int Win, hipStream_t s) {
+    const int H = (Hin + L.stride - 1) / L.stride, W = (Win + L.stride - 1) / L.stride;
+    ConvIO io{};
+    io.src0 = Act{const_cast<float*>(x), xbs, L.Cin};
+    io.out0 = Act{y, ybs, L.Cout};
+    if (res) io.aux0 = Act{const_cast<float*>(res), rbs, L.Cout};
+    io.Hin = Hin; io.Win = Win;
+    io.flags = flags;
+    io.src_tiled = x_tiled;
+    io.dst_tiled = y_tiled;
+    return launch_conv(L, base, io, EPI_AFFINE, B, H, W, s);
+}
+
+// ------------------------------------------------------------------------------------------ stem: 7x7 stride 2, 3 -> 64
+// One workgroup = a 8x32 output region (walked as 8 sub-tiles of 4x8, so a wave stores two 128-B lines of the
+// tile-major layout) x 32 of the 64 output channels.  The 3 x 21 x 69 input patch is staged in LDS; a thread keeps its
+// 147-tap neighbourhood in registers and the (wave-uniform) weights stream through the scalar cache.
+// grid (regions, 2 channel halves, N)
+__global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float* __restrict__ out, long obs, int Hin, int Win, int H, int W,
+                                                   int tiles_x, Lay lay) {
+    __shared__ float patch[3][21][72];
+    const int tid = threadIdx.x;
+    const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
+    const int n = blockIdx.z, co0 = blockIdx.y * 32;
+    const long HWin = (long)Hin * Win;
+    const float* src = x + (long)n * 3 * HWin;
+    for (int e = tid; e < 3 * 21 * 69; e += 256) {
+        const int c = e / (21 * 69), rem = e % (21 * 69);
+        const int pr = rem / 69, pc = rem % 69;
+        const int gy = ty0 * 2 + pr - 3, gx = tx0 * 2 + pc - 3;
+        patch[c][pr][pc] = (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) ? src[c * HWin + (long)gy * Win + gx] : 0.f;
+    }
+    __syncthreads();
+    const int st = tid >> 5, within = tid & 31;
+    const int ty = (st >> 2) * 4 + (within >> 3), tx = (st & 3) * 8 + (within & 7);
+    float v[147];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) v[c * 49 + dy * 7 + dx] = patch[c][2 * ty + dy][2 * tx + dx];
+    const int y = ty0 + ty, xx = tx0 + tx;
+    const bool ok = y < H && xx < W;
+    float* o = out + (long)n * obs + (ok ? pix_off(lay, y, xx) : 0);
+    for (int co = co0; co < co0 + 32; ++co) {
+        const float* wc = w + (long)co * 147;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 147; ++i) acc = fmaf(wc[i], v[i], acc);
+        acc = fmaf(acc, scale[co], shift[co]);
+        if (ok) o[(long)co * lay.plane] = fmaxf(acc, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ encoder plan
+constexpr int ENC_BLOCKS = 6;
+struct EncPlan {
+    nnd_encoder_desc d;
+    int64_t stem_w, stem_scale, stem_shift;  // raw (64,3,7,7) weights + folded norm
+    ConvLayer c1[ENC_BLOCKS], c2[ENC_BLOCKS], ds[ENC_BLOCKS];
+    int64_t base1[ENC_BLOCKS], base2[ENC_BLOCKS], based[ENC_BLOCKS];
+    ConvLayer out;  // conv2 1x1
+    int64_t base_out;
+    ConvLayer cnet;  // cnet_proj 3x3 (optional)
+    int64_t base_cnet;
+    int64_t total;
+    int planes[ENC_BLOCKS], strides[ENC_BLOCKS], inpl[ENC_BLOCKS];
+};
+
+static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
+    NND_REQUIRE(d, "encoder: null descriptor");
+    NND_REQUIRE(d->output_dim > 0 && d->cnet_dim >= 0, "encoder: bad output_dim / cnet_dim");
+    NND_REQUIRE(d->norm == 0 || d->norm == 1, "encoder: norm must be 0 (none) or 1 (batch, eval); instance / group norm "
+                "need per-sample statistics and are not built");
+    p->d = *d;
+    int64_t off = 0;
+    p->stem_w = off; off += 64 * 147;
+    p->stem_scale = off; off += 64;
+    p->stem_shift = off; off += 64;
+    const int dims[3] = {64, 96, 128}, strd[3] = {1, 2, 2};
+    int cin = 64;
+    for (int i = 0; i < ENC_BLOCKS; ++i) {
+        const int dim = dims[i / 2], st = (i % 2 == 0) ? strd[i / 2] : 1;
+        p->planes[i] = dim; p->strides[i] = st; p->inpl[i] = cin;
+        int64_t t;
+        nnd_conv_desc a{dim, cin, 3, 3, st}, b{dim, dim, 3, 3, 1}, c{dim, cin, 1, 1, st};
+        int rc;
+        if ((rc = conv_layer(&a, &p->c1[i], &t)) != NND_OK) return rc;
+        p->base1[i] = off; off += t;
+        if ((rc = conv_layer(&b, &p->c2[i], &t)) != NND_OK) return rc;
+        p->base2[i] = off; off += t;
+        if ((rc = conv_layer(&c, &p->ds[i], &t)) != NND_OK) return rc;
+        p->based[i] = off; off += t;
+        cin = dim;
+    }
+    int64_t t;
+    nnd_conv_desc o{d->output_dim, 128, 1, 1, 1};
+    int rc = conv_layer(&o, &p->out, &t);
+    if (rc != NND_OK) return rc;
+    p->base_out = off; off += t;
+    p->base_cnet = off;
+    if (d->cnet_dim > 0) {
+        nnd_conv_desc c{d->cnet_dim, d->output_dim, 3, 3, 1};
+        if ((rc = conv_layer(&c, &p->cnet, &t)) != NND_OK) return rc;
+        off += t;
+    }
+    p->total = off;
+    return NND_OK;
+}
+
+static int64_t enc_buf_floats(int N, int H, int W) {  // one activation buffer: 64 channels at 1/2 resolution
+    const int h2 = (H + 1) / 2, w2 = (W + 1) / 2;
+    return ((int64_t)N * 64 * tiled_plane(h2, w2) + 63) / 64 * 64;
+}
+
+}  // namespace nnd
+
+using namespace nnd;
+
+extern "C" {
+
+int64_t nnd_conv_packed_floats(const nnd_conv_desc* desc) {
+    ConvLayer L;
+    int64_t total;
+    if (conv_layer(desc, &L, &total) != NND_OK) return NND_ERR_INVALID;
+    return total;
+}
+
+int nnd_conv_pack(const nnd_conv_desc* desc, const float* w, const float* bias, const float* bn_gamma, const float* bn_beta,
+                  const float* bn_mean, const float* bn_var, float bn_eps, float* packed_host) {
+    ConvLayer L;
+    int rc = conv_layer(desc, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(w && packed_host, "conv_pack: null pointer");
+    NND_REQUIRE(!bn_gamma || (bn_beta && bn_mean && bn_var), "conv_pack: incomplete batch-norm parameters");
+    pack_conv_norm(L, w, bias, bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, packed_host);
+    return NND_OK;
+}
+
+int nnd_conv_forward(const nnd_conv_desc* desc, const float* packed_dev, const float* x, const float* residual, float* y,
+                     int B, int Hin, int Win, int relu, int relu_after_residual, void* stream) {
+    ConvLayer L;
+    int rc = conv_layer(desc, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev && x && y && B > 0 && Hin > 0 && Win > 0, "conv_forward: bad argument");
+    const int H = (Hin + L.stride - 1) / L.stride, W = (Win + L.stride - 1) / L.stride;
+    return run_conv_norm(L, packed_dev, x, (int64_t)L.Cin * Hin * Win, false, residual, (int64_t)L.Cout * H * W, y,
+                         (int64_t)L.Cout * H * W, false, (relu ? 1 : 0) | (relu_after_residual ? 2 : 0), B, Hin, Win,
+                         (hipStream_t)stream);
+}
+
+int nnd_encoder_num_tensors(const nnd_encoder_desc* desc) {
+    EncPlan p;
+    if (make_enc_plan(desc, &p) != NND_OK) return NND_ERR_INVALID;
+    return 6 * (1 + 3 * ENC_BLOCKS + 1 + (desc->cnet_dim > 0 ? 1 : 0));
+}
+
+int64_t nnd_encoder_packed_floats(const nnd_encoder_desc* desc) {
+    EncPlan p;
+    if (make_enc_plan(desc, &p) != NND_OK) return NND_ERR_INVALID;
+    return p.total;
+}
+
+int64_t nnd_encoder_workspace_floats(const nnd_encoder_desc* desc, int N, int H, int W) {
+    EncPlan p;
+    if (make_enc_plan(desc, &p) != NND_OK || N <= 0 || H <= 0 || W <= 0) return NND_ERR_INVALID;
+    return 4 * enc_buf_floats(N, H, W);
+}
+
+// tensors: units of 6 pointers (weight, bias, norm gamma, norm beta, running mean, running var; the last four NULL
+// when the conv has no norm) in this order: conv1 | per block (layer1.0 ... layer3.1): conv1, conv2, downsample.0 |
+// conv2 | cnet_proj.0 (only if cnet_dim > 0).
+int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* t, float bn_eps, float* packed_host) {
+    EncPlan p;
+    int rc = make_enc_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(t && packed_host, "encoder_pack: null pointer");
+    const int units = 1 + 3 * ENC_BLOCKS + 1 + (desc->cnet_dim > 0 ? 1 : 0);
+    for (int u = 0; u < units; ++u) {
+        NND_REQUIRE(t[6 * u] && t[6 * u + 1], "encoder_pack: unit %d: null weight / bias", u);
+        const bool has_norm = t[6 * u + 2] != nullptr;
+        NND_REQUIRE(!has_norm || (t[6 * u + 3] && t[6 * u + 4] && t[6 * u + 5]), "encoder_pack: unit %d: incomplete norm", u);
+        const bool want_norm = desc->norm == 1 && u < units - 1 - (desc->cnet_dim > 0 ? 1 : 0);
+        NND_REQUIRE(has_norm == want_norm, "encoder_pack: unit %d: norm parameters %s", u, want_norm ? "missing" : "unexpected");
+    }
+    memset(packed_host, 0, sizeof(float) * p.total);
+    auto unit = [&](int u) { return t + 6 * u; };
+    {  // stem: raw weights + folded norm
+        const float* const* q = unit(0);
+        memcpy(packed_host + p.stem_w, q[0], sizeof(float) * 64 * 147);
+        for (int c = 0; c < 64; ++c) {
+            double sc = 1.0, sh = q[1][c];
+            if (q[2]) {
+                sc = (double)q[2][c] / std::sqrt((double)q[5][c] + (double)bn_eps);
+                sh = ((double)q[1][c] - (double)q[4][c]) * sc + (double)q[3][c];
+            }
+            packed_host[p.stem_scale + c] = (float)sc;
+            packed_host[p.stem_shift + c] = (float)sh;
+        }
+    }
+    int u = 1;
+    for (int i = 0; i < ENC_BLOCKS; ++i) {
+        const float* const* a = unit(u++);
+        pack_conv_norm(p.c1[i], a[0], a[1], a[2], a[3], a[4], a[5], bn_eps, packed_host + p.base1[i]);
+        const float* const* b = unit(u++);
+        pack_conv_norm(p.c2[i], b[0], b[1], b[2], b[3], b[4], b[5], bn_eps, packed_host + p.base2[i]);
+        const float* const* c = unit(u++);
+        pack_conv_norm(p.ds[i], c[0], c[1], c[2], c[3], c[4], c[5], bn_eps, packed_host + p.based[i]);
+    }
+    const float* const* o = unit(u++);
+    pack_conv_norm(p.out, o[0], o[1], nullptr, nullptr, nullptr, nullptr, bn_eps, packed_host + p.base_out);
+    if (desc->cnet_dim > 0) {
+        const float* const* c = unit(u++);
+        pack_conv_norm(p.cnet, c[0], c[1], nullptr, nullptr, nullptr, nullptr, bn_eps, packed_host + p.base_cnet);
+    }
+    return NND_OK;
+}
+
+// frames (N,3,H,W) NCHW -> fmap (N,output_dim,H8,W8) NCHW, H8 = ceil(ceil(ceil(H/2)/2)/2); cnet_out (optional, needs
+// cnet_dim > 0): ReLU(cnet_proj(fmap[:n_cnet])) (n_cnet,cnet_dim,H8,W8).
+int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const float* frames, float* fmap, float* cnet_out,
+                        int n_cnet, float* workspace, int N, int H, int W, void* stream) {
+    EncPlan p;
+    int rc = make_enc_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed && frames && fmap && workspace && N > 0 && H > 0 && W > 0, "encoder_forward: bad argument");
+    NND_REQUIRE(!cnet_out || (desc->cnet_dim > 0 && n_cnet > 0 && n_cnet <= N), "encoder_forward: cnet_out needs cnet_dim > 0 and 0 < n_cnet <= N");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t bufsz = enc_buf_floats(N, H, W);
+    float* buf[4] = {workspace, workspace + bufsz, workspace + 2 * bufsz, workspace + 3 * bufsz};
+    int h = (H + 1) / 2, w = (W + 1) / 2;
+    {  // stem -> buf[0]
+        const Lay lay = make_lay(h, w, true);
+        const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 8);
+        hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 2, N), dim3(256), 0, s, frames, packed + p.stem_w,
+                           packed + p.stem_scale, packed + p.stem_shift, buf[0], (long)(64 * lay.plane), H, W, h, w, tiles_x, lay);
+        NND_LAUNCH_CHECK();
+    }
+    int cur = 0;  // buffer holding the block input
+#define NND_TRY(x)                    \
+    do {                              \
+        if ((rc = (x)) != NND_OK) return rc; \
+    } while (0)
+    for (int i = 0; i < ENC_BLOCKS; ++i) {
+        const int st = p.strides[i], cin = p.inpl[i], dim = p.planes[i];
+        const int ho = (h + st - 1) / st, wo = (w + st - 1) / st;
+        const int64_t pin = tiled_plane(h, w), pout = tiled_plane(ho, wo);
+        float* x = buf[cur];
+        float* y = buf[(cur + 1) & 3];
+        float* sc = buf[(cur + 2) & 3];
+        float* o = buf[(cur + 3) & 3];
+        NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 1, N, h, w, s));
+        NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s));
+        NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, sc, dim * pout, o, dim * pout, true, 3, N, ho, wo, s));
+        cur = (cur + 3) & 3;
+        h = ho; w = wo;
+    }
+    const int64_t pl = tiled_plane(h, w);
+    NND_TRY(run_conv_norm(p.out, packed + p.base_out, buf[cur], 128 * pl, true, nullptr, 0, fmap, (int64_t)desc->output_dim * h * w,
+                          false, 0, N, h, w, s));
+    if (cnet_out)
+        NND_TRY(run_conv_norm(p.cnet, packed + p.base_cnet, fmap, (int64_t)desc->output_dim * h * w, false, nullptr, 0, cnet_out,
+                              (int64_t)desc->cnet_dim * h * w, false, 1, n_cnet, h, w, s));
+#undef NND_TRY
+    return NND_OK;
+}
+
+}  // extern "C"

@@ -132,7 +132,8 @@ static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
 // ------------------------------------------------------------------------- small kernels
 // encoder.convf1: 7x7, Cin = FC (1 or 2) -> 128, ReLU.  K = 49*FC is too shallow for the MFMA path;
 // each thread keeps its 49*FC-tap neighbourhood in registers and the (wave-uniform) weights come in
-// through the scalar cache.  grid (tiles of 8x32 px, 128/32 channel groups, B), 256 threads.
+// through the scalar cache.  grid (regions of 8x32 px, 128/16 channel groups, B), 256 threads; a region is walked as
+// 8 sub-tiles of 4x8 pixels so that a wave's stores are two full 128-B lines of the tile-major layout.
 template <int FC>
 __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ flow, long fbs, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out, long obs,
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
     __shared__ float patch[FC][14][40];
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
-    const int b = blockIdx.z, co0 = blockIdx.y * 32;
+    const int b = blockIdx.z, co0 = blockIdx.y * 16;
     const long HW = lay.plane;
     for (int e = tid; e < FC * 14 * 38; e += 256) {
         int c = e / (14 * 38), rem = e % (14 * 38);
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
         patch[c][pr][pc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? flow[b * fbs + c * HW + pix_off(lay, gy, gx)] : 0.f;
     }
     __syncthreads();
-    const int ty = tid >> 5, tx = tid & 31;
+    const int st = tid >> 5, within = tid & 31;  // sub-tile (2 rows x 4 cols of them), pixel inside it
+    const int ty = (st >> 2) * 4 + (within >> 3), tx = (st & 3) * 8 + (within & 7);
     float v[FC * 49];
 #pragma unroll
     for (int c = 0; c < FC; ++c)
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
             for (int dx = 0; dx < 7; ++dx) v[c * 49 + dy * 7 + dx] = patch[c][ty + dy][tx + dx];
     const int y = ty0 + ty, x = tx0 + tx;
     const bool ok = y < H && x < W;
-    for (int co = co0; co < co0 + 32; ++co) {
+    for (int co = co0; co < co0 + 16; ++co) {
         const float* wc = w + (long)co * (FC * 49);
         float acc = 0.f;
 #pragma unroll
@@ -419,7 +421,7 @@ static int run_conv(const Plan& p, const float* blob, const Bufs& w, int id, Act
 static int run_convf1(const Plan& p, const float* blob, const float* flow, int64_t fbs, float* out, int B, int H, int W,
                       hipStream_t s) {
     const int tiles_x = cdiv(W, 32), tiles_y = cdiv(H, 8);
-    dim3 grid(tiles_x * tiles_y, 4, B), block(256);
+    dim3 grid(tiles_x * tiles_y, 8, B), block(256);
     const Lay lay = make_lay(H, W, true);
     const int64_t n = lay.plane;
     if (p.d.flow_channels == 1)

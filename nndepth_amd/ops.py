@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import NndError, UpdateBlockDesc, check, lib
+from ._lib import ConvDesc, EncoderDesc, NndError, UpdateBlockDesc, check, lib
 
 
 def _dev(*tensors: torch.Tensor) -> torch.device:
@@ -376,3 +376,119 @@ def agcl_corr_offset(fmap1: torch.Tensor, fmap2: torch.Tensor, flow: torch.Tenso
         check(lib.nnd_agcl_corr_offset(_p(fmap1), _p(fmap2), _p(flow), _p(extra_offset), _p(out), N, C, H, W,
                                        int(bool(small_patch)), _stream(d)), "agcl_corr_offset")
     return out
+
+
+# ------------------------------------------------------------------ conv + folded norm, encoder (include/nndepth_amd.h)
+def _host(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().to("cpu", torch.float32).contiguous()
+
+
+class ConvNorm:
+    """nn.Conv2d [+ BatchNorm2d(eval)] [+ ReLU] [+ residual add + ReLU] as one MFMA convolution (stride 1 or 2,
+    1x1 / 3x3; 1x5 / 5x1 at stride 1).  `bn` = (weight, bias, running_mean, running_var) or None."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, bn=None, eps: float = 1e-5,
+                 device="cuda"):
+        Cout, Cin, KH, KW = (int(v) for v in weight.shape)
+        self.desc = ConvDesc(Cout, Cin, KH, KW, int(stride))
+        n = int(lib.nnd_conv_packed_floats(C.byref(self.desc)))
+        if n <= 0:
+            check(n, "conv_packed_floats")
+        w, b = _host(weight), _host(bias)
+        g, be, m, v = (_host(t) for t in bn) if bn is not None else (None, None, None, None)
+        blob = torch.empty(n, dtype=torch.float32)
+        check(lib.nnd_conv_pack(C.byref(self.desc), _p(w), _p(b), _p(g), _p(be), _p(m), _p(v), float(eps), _p(blob)), "conv_pack")
+        self.packed = blob.to(device)
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, relu: bool = False,
+                 relu_after_residual: bool = False) -> torch.Tensor:
+        d = _dev(x, self.packed)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        if Cin != self.desc.Cin:
+            raise NndError(f"conv: input has {Cin} channels, weights expect {self.desc.Cin}")
+        st = self.desc.stride
+        Ho, Wo = (H + st - 1) // st, (W + st - 1) // st
+        y = torch.empty((B, self.desc.Cout, Ho, Wo), dtype=torch.float32, device=d)
+        if residual is not None:
+            residual = residual.contiguous()
+            _dev(residual)
+            if residual.shape != y.shape:
+                raise NndError(f"conv: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
+        with torch.cuda.device(d):
+            check(lib.nnd_conv_forward(C.byref(self.desc), _p(self.packed), _p(x), _p(residual), _p(y), B, H, W,
+                                       int(relu), int(relu_after_residual), _stream(d)), "conv_forward")
+        return y
+
+
+ENCODER_BLOCKS = ("layer1.0", "layer1.1", "layer2.0", "layer2.1", "layer3.0", "layer3.1")
+
+
+class EncoderEngine:
+    """BasicEncoder (+ optional cnet_proj) on the HIP encoder (csrc/encoder.hip).  Parameters come from state-dict
+    style mappings: `enc_sd` with the reference's BasicEncoder keys (conv1.weight, norm1.running_mean,
+    layer1.0.conv1.weight, layer1.0.downsample.0.weight, layer1.0.norm3.weight, ..., conv2.bias) and, optionally,
+    `cnet_sd` with `0.weight` / `0.bias` of the cnet_proj Sequential."""
+
+    def __init__(self, output_dim: int, norm: str = "batch", cnet_dim: int = 0):
+        if norm not in ("batch", "none"):
+            raise NndError(f"EncoderEngine: norm_fn '{norm}' is not built in HIP (batch in eval mode, none)")
+        self.norm = norm
+        self.desc = EncoderDesc(int(output_dim), 1 if norm == "batch" else 0, int(cnet_dim))
+        n = int(lib.nnd_encoder_packed_floats(C.byref(self.desc)))
+        if n <= 0:
+            check(n, "encoder_packed_floats")
+        self.packed_floats = n
+        self.packed = None
+        self._ws = None
+
+    def _units(self, enc_sd, cnet_sd):
+        def unit(conv: str, norm: Optional[str]):
+            t = [enc_sd[conv + ".weight"], enc_sd[conv + ".bias"]]
+            if norm is not None and self.norm == "batch":
+                t += [enc_sd[norm + ".weight"], enc_sd[norm + ".bias"], enc_sd[norm + ".running_mean"], enc_sd[norm + ".running_var"]]
+            else:
+                t += [None] * 4
+            return t
+        units = [unit("conv1", "norm1")]
+        for b in ENCODER_BLOCKS:
+            units += [unit(f"{b}.conv1", f"{b}.norm1"), unit(f"{b}.conv2", f"{b}.norm2"), unit(f"{b}.downsample.0", f"{b}.norm3")]
+        units.append(unit("conv2", None))
+        if self.desc.cnet_dim > 0:
+            units.append([cnet_sd["0.weight"], cnet_sd["0.bias"], None, None, None, None])
+        return units
+
+    def load(self, enc_sd, cnet_sd=None, eps: float = 1e-5, device="cuda") -> "EncoderEngine":
+        if self.desc.cnet_dim > 0 and cnet_sd is None:
+            raise NndError("EncoderEngine: cnet_dim > 0 needs the cnet_proj parameters")
+        host = [_host(t) for u in self._units(enc_sd, cnet_sd) for t in u]
+        n = int(lib.nnd_encoder_num_tensors(C.byref(self.desc)))
+        if n != len(host):
+            raise NndError(f"EncoderEngine: {len(host)} tensors, the library expects {n}")
+        arr = (C.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in host])
+        blob = torch.empty(self.packed_floats, dtype=torch.float32)
+        check(lib.nnd_encoder_pack(C.byref(self.desc), arr, float(eps), _p(blob)), "encoder_pack")
+        self.packed = blob.to(device)
+        return self
+
+    def forward(self, frames: torch.Tensor, n_cnet: int = 0):
+        """frames (N,3,H,W) -> (fmap (N,output_dim,H/8,W/8), cnet (n_cnet,cnet_dim,H/8,W/8) or None)."""
+        if self.packed is None:
+            raise NndError("EncoderEngine: parameters not loaded")
+        d = _dev(frames, self.packed)
+        frames = frames.contiguous()
+        N, c, H, W = frames.shape
+        if c != 3:
+            raise NndError(f"encoder: frames have {c} channels, expected 3")
+        h8, w8 = H, W
+        for _ in range(3):
+            h8, w8 = (h8 + 1) // 2, (w8 + 1) // 2
+        fmap = torch.empty((N, self.desc.output_dim, h8, w8), dtype=torch.float32, device=d)
+        cnet = torch.empty((n_cnet, self.desc.cnet_dim, h8, w8), dtype=torch.float32, device=d) if n_cnet > 0 else None
+        need = int(lib.nnd_encoder_workspace_floats(C.byref(self.desc), N, H, W))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != d:
+            self._ws = torch.empty(need, dtype=torch.float32, device=d)
+        with torch.cuda.device(d):
+            check(lib.nnd_encoder_forward(C.byref(self.desc), _p(self.packed), _p(frames), _p(fmap), _p(cnet), n_cnet,
+                                          _p(self._ws), N, H, W, _stream(d)), "encoder_forward")
+        return fmap, cnet

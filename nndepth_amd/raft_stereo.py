@@ -5,7 +5,8 @@ nndepth/models/raft_stereo/configs.py:11-23), `state_dict()` keys and `forward(f
 -> List[{"up_disp": Tensor}]` (nndepth/models/raft_stereo/model.py:17-163), so the reference's
 inference / evaluate scripts can use it unchanged.  Inside `forward()`:
 
-    encoder + cnet_proj      PyTorch-ROCm (adjacent row)
+    encoder + cnet_proj      HIP, ONE C-ABI call (csrc/encoder.hip: nnd_encoder_forward; eval-mode BatchNorm folded);
+                             `hip_encoder=False` / training mode / other norms: PyTorch-ROCm        model.py:107-109
     corr pyramid build       HIP  (csrc/corr1d.hip)                     model.py:124
     for iters: lookup -> update block -> coords += delta -> convex upsample
                              HIP, ONE C-ABI call for the whole loop     model.py:130-137
@@ -19,6 +20,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from . import ops
 from .blocks import BasicUpdateBlock
 from .cost_volume import CorrBlock1D
 from .encoder import BasicEncoder
@@ -40,12 +42,14 @@ class BaseRAFTStereo(nn.Module):
     def __init__(self, iters: int = 12, fnet_dim: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, **kwargs):
+                 fused_loop: bool = True, hip_encoder: bool = True, **kwargs):
         super().__init__()
         self.iters, self.fnet_dim, self.hidden_dim, self.context_dim = iters, fnet_dim, hidden_dim, context_dim
         self.corr_levels, self.corr_radius = corr_levels, corr_radius
         self.tracing, self.include_preprocessing = tracing, include_preprocessing
         self.fused_loop = fused_loop
+        self.hip_encoder = hip_encoder
+        self._enc_engine, self._enc_version = None, None
         self.fnet = BasicEncoder(output_dim=fnet_dim)
         self.cnet_proj = nn.Sequential(nn.Conv2d(fnet_dim, context_dim + hidden_dim, 3, padding=1), nn.ReLU(False))
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=corr_levels * (2 * corr_radius + 1),
@@ -63,7 +67,24 @@ class BaseRAFTStereo(nn.Module):
         B, _, H, W = fmap1.shape
         return torch.arange(W, device=fmap1.device).float()[None, None, None, :].repeat(B, 1, H, 1)
 
+    def _encoder_engine(self, device) -> "ops.EncoderEngine":
+        """(Re)pack fnet + cnet_proj for the HIP encoder if their parameters / buffers changed."""
+        tensors = list(self.fnet.state_dict().values()) + list(self.cnet_proj.state_dict().values())
+        v = (tuple((t.data_ptr(), t._version) for t in tensors), str(device))
+        if v != self._enc_version:
+            if self._enc_engine is None:
+                self._enc_engine = ops.EncoderEngine(self.fnet_dim, self.fnet.norm_fn, self.context_dim + self.hidden_dim)
+            self._enc_engine.load(self.fnet.state_dict(), self.cnet_proj.state_dict(), eps=1e-5, device=device)
+            self._enc_version = v
+        return self._enc_engine
+
     def forward_fnet(self, frame1, frame2):
+        if (self.hip_encoder and frame1.is_cuda and not self.training and self.fnet.norm_fn in ("batch", "none")
+                and self.fnet.dropout is None):
+            # BasicEncoder + cnet_proj in ONE C-ABI call (csrc/encoder.hip); eval-mode BatchNorm folded into the convs
+            B = frame1.shape[0]
+            fmaps, cnet = self._encoder_engine(frame1.device).forward(torch.cat([frame1, frame2], 0).float(), n_cnet=B)
+            return fmaps[:B], fmaps[B:], cnet
         fmap1, fmap2 = self.fnet([frame1, frame2])
         return fmap1, fmap2, self.cnet_proj(fmap1)
 

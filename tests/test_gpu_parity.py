@@ -497,3 +497,60 @@ def test_cre_fused_stage_matches_seam_by_seam(cre_sd):
     errs = [(a["up_disp"] - b["up_disp"]).abs().max().item() for a, b in zip(fused, seam)]
     print("\ncre fused vs seam-by-seam:", " ".join(f"{e:.2e}" for e in errs))
     assert max(errs) <= 5e-5
+
+
+# ------------------------------------------------------------ conv + folded norm, encoder
+@pytest.mark.parametrize("Cout,Cin,K,stride,B,H,W", [
+    (96, 64, 3, 2, 2, 34, 60), (128, 96, 3, 2, 1, 17, 31), (96, 64, 1, 2, 2, 34, 60), (128, 96, 1, 2, 1, 9, 13),
+    (64, 64, 3, 1, 2, 20, 36), (96, 96, 3, 1, 1, 17, 30), (256, 128, 1, 1, 2, 9, 15), (70, 40, 3, 2, 1, 11, 22)])
+def test_conv_norm_vs_torch(Cout, Cin, K, stride, B, H, W):
+    """nnd_conv_forward: conv (stride 1/2) + eval BatchNorm + ReLU + residual + ReLU against the same PyTorch CPU ops."""
+    from nndepth_amd import ops
+    torch.manual_seed(Cout + Cin + K + stride)
+    w = torch.randn(Cout, Cin, K, K) * (2.0 / (Cin * K * K)) ** 0.5
+    b = torch.randn(Cout) * 0.1
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5)
+    x = torch.randn(B, Cin, H, W)
+    ref = torch.nn.functional.conv2d(x, w, b, stride=stride, padding=K // 2)
+    ref_bn = torch.nn.functional.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    res = torch.randn_like(ref)
+    conv_bn = ops.ConvNorm(w, b, stride, bn, 1e-5, DEV)
+    conv_plain = ops.ConvNorm(w, b, stride, None, 1e-5, DEV)
+    assert (conv_plain(x.to(DEV)).cpu() - ref).abs().max() <= 2e-5
+    assert (conv_bn(x.to(DEV), relu=True).cpu() - torch.relu(ref_bn)).abs().max() <= 3e-5
+    got = conv_bn(x.to(DEV), residual=res.to(DEV), relu=True, relu_after_residual=True).cpu()
+    assert (got - torch.relu(res + torch.relu(ref_bn))).abs().max() <= 3e-5
+
+
+@pytest.mark.parametrize("H,W,B", [(96, 160, 1), (120, 200, 2)])
+def test_encoder_small_vs_oracle(raft_sd, R, H, W, B):
+    """BasicEncoder + cnet_proj in HIP against the oracle restatement (eval BatchNorm), small shapes incl. sizes that
+    are not multiples of 8 at the lower levels."""
+    from nndepth_amd import ops, weightgen
+    fr1, fr2 = weightgen.synthetic_frames(7, B, H, W)
+    enc_sd = {k[len("fnet."):]: v for k, v in raft_sd.items() if k.startswith("fnet.")}
+    cnet_sd = {k[len("cnet_proj."):]: v for k, v in raft_sd.items() if k.startswith("cnet_proj.")}
+    eng = ops.EncoderEngine(256, "batch", 192).load(enc_sd, cnet_sd, device=DEV)
+    fm, cnet = eng.forward(torch.cat([fr1, fr2], 0).to(DEV), n_cnet=B)
+    exp = R.basic_encoder(raft_sd, "fnet", torch.cat([fr1, fr2], 0))
+    exp_c = torch.relu(torch.nn.functional.conv2d(exp[:B], raft_sd["cnet_proj.0.weight"], raft_sd["cnet_proj.0.bias"], padding=1))
+    e1, e2 = (fm.cpu() - exp).abs().max().item(), (cnet.cpu() - exp_c).abs().max().item()
+    print(f"\nencoder {H}x{W} B={B}: fmap max-abs {e1:.2e} (|fmap| max {exp.abs().max():.2f}), cnet {e2:.2e}")
+    assert e1 <= 5e-5 and e2 <= 5e-5
+
+
+def test_encoder_fullsize_vs_oracle_and_pytorch_path(raft_sd, tartanair_frames, R):
+    """544x960 TartanAir pair: HIP encoder vs the oracle (CPU) and vs the PyTorch-ROCm path of the same module."""
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    m = BaseRAFTStereo(iters=2, context_dim=64)
+    m.load_state_dict(raft_sd)
+    m = m.to(DEV).eval()
+    f1, f2 = (t.to(DEV) for t in tartanair_frames)
+    a1, a2, ac = m.forward_fnet(f1, f2)
+    m.hip_encoder = False
+    b1, b2, bc = m.forward_fnet(f1, f2)
+    exp = R.basic_encoder(raft_sd, "fnet", torch.cat(tartanair_frames, 0))
+    e_hip = (torch.cat([a1, a2]).cpu() - exp).abs().max().item()
+    e_pt = (torch.cat([b1, b2]).cpu() - exp).abs().max().item()
+    print(f"\nencoder 544x960: HIP vs oracle {e_hip:.2e}, PyTorch-ROCm (MIOpen) vs oracle {e_pt:.2e}, cnet HIP vs PyTorch {(ac - bc).abs().max().item():.2e}")
+    assert e_hip <= 5e-5
