@@ -126,3 +126,49 @@ def test_update_block_state_dict_keys_match_reference_order():
     ub2 = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=128, gru="conv_gru", flow_channel=2)
     assert list(ub2.state_dict().keys()) == ops.update_block_keys("conv_gru")
     assert tuple(ub2.state_dict()["mask.2.weight"].shape) == (576, 256, 1, 1)
+
+
+def test_conv_norm_pack_folds_batchnorm_on_host():
+    """nnd_conv_pack (HOST): the eval-mode BatchNorm is folded into scale = gamma / sqrt(var + eps) and
+    shift = (bias - mean) * scale + beta, stored behind the fragment-ordered weights."""
+    from nndepth_amd._lib import lib, ConvDesc
+    Cout, Cin = 40, 24
+    g = torch.Generator().manual_seed(3)
+    w, b = torch.randn(Cout, Cin, 3, 3, generator=g), torch.randn(Cout, generator=g)
+    gamma, beta, mean = (torch.randn(Cout, generator=g) for _ in range(3))
+    var = torch.rand(Cout, generator=g) + 0.5
+    for stride, ci_t in ((1, 32), (2, 16)):
+        d = ConvDesc(Cout, Cin, 3, 3, stride)
+        n = lib.nnd_conv_packed_floats(C.byref(d))
+        ncb, nchunks = 2, -(-Cin // ci_t)
+        assert n == ncb * nchunks * 9 * ci_t * 32 + 2 * ncb * 32
+        blob = torch.zeros(n)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        assert lib.nnd_conv_pack(C.byref(d), P(w), P(b), P(gamma), P(beta), P(mean), P(var), 1e-5, P(blob)) == 0
+        scale = gamma.double() / torch.sqrt(var.double() + 1e-5)
+        shift = (b.double() - mean.double()) * scale + beta.double()
+        wf = ncb * nchunks * 9 * ci_t * 32
+        assert torch.allclose(blob[wf:wf + Cout].double(), shift, atol=1e-6)
+        assert torch.allclose(blob[wf + 64:wf + 64 + Cout].double(), scale, atol=1e-6)
+        assert not blob[wf + Cout:wf + 64].any()  # padded channels: shift 0
+        # no norm: scale 1, shift = bias
+        assert lib.nnd_conv_pack(C.byref(d), P(w), P(b), None, None, None, None, 1e-5, P(blob)) == 0
+        assert torch.equal(blob[wf:wf + Cout], b) and bool((blob[wf + 64:wf + 64 + Cout] == 1).all())
+    assert lib.nnd_conv_packed_floats(C.byref(ConvDesc(8, 8, 1, 5, 2))) < 0  # 1x5 at stride 2 is not built
+
+
+def test_encoder_pack_host(raft_sd):
+    from nndepth_amd import ops
+    from nndepth_amd._lib import lib, NndError
+    eng = ops.EncoderEngine(256, "batch", 192)
+    assert lib.nnd_encoder_num_tensors(C.byref(eng.desc)) == 6 * (1 + 18 + 1 + 1)
+    enc_sd = {k[len("fnet."):]: v for k, v in raft_sd.items() if k.startswith("fnet.")}
+    cnet_sd = {k[len("cnet_proj."):]: v for k, v in raft_sd.items() if k.startswith("cnet_proj.")}
+    eng.load(enc_sd, cnet_sd, device="cpu")  # host-only packing
+    assert eng.packed.numel() == eng.packed_floats and torch.isfinite(eng.packed).all()
+    assert torch.equal(eng.packed[:64 * 147].view(64, 3, 7, 7), enc_sd["conv1.weight"])  # stem weights kept raw
+    assert lib.nnd_encoder_workspace_floats(C.byref(eng.desc), 2, 544, 960) == 4 * 2 * 64 * 272 * 480
+    with pytest.raises(NndError):
+        ops.EncoderEngine(256, "instance", 0)
+    with pytest.raises(NndError):
+        ops.EncoderEngine(256, "batch", 192).load(enc_sd, None, device="cpu")
