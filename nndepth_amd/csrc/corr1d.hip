@@ -253,6 +253,87 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
     return NND_OK;
 }
 
+// Fused lookup + encoder.convc1 (1x1, cor_planes -> 256, ReLU) for the refinement loop: one workgroup = one 4x8 pixel
+// tile x all 256 output channels (8 waves).  The cor_planes sampled values of the tile are computed straight into the
+// LDS B-operand (same arithmetic, same op order as corr1d_lookup_kernel), then every wave runs its cor_planes/2 MFMAs
+// against the packed convc1 weights (conv_mfma fragment order, CI_T = 32) and stores relu(acc + bias) as one 128-B line
+// per (channel, half-wave) of the tile-major c1 buffer.  Saves a launch and the (B,cor_planes,H,W) round trip; the
+// accumulation order is the one of conv_mfma with ks = 1, so the result is bit-identical to lookup -> convc1.
+__global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                            const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long obs, LookupArgs a, int tiles_x) {
+    __shared__ float xs[64 * 32];  // [channel][pixel of the tile]; channels >= cor_planes stay zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
+    const int ntap = 2 * a.radius + 1, nch = a.num_levels * ntap;
+    const long HW = (long)a.H * a.W;
+    for (int e = tid; e < 64 * 32; e += 512) {
+        const int ch = e >> 5, px = e & 31;
+        const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
+        float v = 0.f;
+        if (ch < nch && y < a.H && x < a.W) {
+            const int lvl = ch / ntap, k = ch - lvl * ntap;
+            const int w2 = a.L.width[lvl];
+            const long pix = (long)y * a.W + x;
+            const float* row = pyr + a.L.off[lvl] + ((long)b * HW + pix) * w2;
+            float xx = (float)(k - a.radius) + coords[(long)b * a.lay.plane + pix_off(a.lay, y, x)] / (float)(1 << lvl);
+            const float wm1 = (float)(w2 - 1);
+            xx = xx / wm1;
+            xx = fminf(fmaxf(xx, 0.f), 1.f);
+            xx = xx * wm1;
+            const float f0 = floorf(xx), f1 = ceilf(xx);
+            const float v0 = row[(int)f0], v1 = row[(int)f1];
+            const float coef = f1 - xx;
+            v = coef * v0 + (1.0f - coef) * v1;
+        }
+        xs[e] = v;
+    }
+    __syncthreads();
+    const int cb = wave;  // 8 waves = 256 output channels
+    const int nchunks = (nch + 31) / 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float4* wb = reinterpret_cast<const float4*>(wpk) + (size_t)cb * nchunks * (4 * 64);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int npair = min(16, (nch - chunk * 32 + 1) / 2);  // k-pairs that hold real channels
+        const float* xb = xs + (chunk * 32 + h2) * 32 + l31;
+        for (int q = 0; q * 4 < npair; ++q) {
+            const float4 av = wb[(size_t)chunk * (4 * 64) + q * 64 + lane];
+            const float as[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q * 4 + j < npair) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], xb[(q * 4 + j) * 64], acc, 0, 0, 0);
+        }
+    }
+    const int y = ty0 + (l31 >> 3), x = tx0 + (l31 & 7);
+    if (y >= a.H || x >= a.W) return;
+    float* o = out + (long)b * obs + pix_off(a.lay, y, x);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+        o[(long)co * a.lay.plane] = fmaxf(acc[reg] + bias[co], 0.f);
+    }
+}
+
+// coords (tile-major) -> c1 = relu(convc1(lookup(coords))) (tile-major, 256 channels); wpk / bias: the packed convc1 layer
+int lookup_convc1_launch(const float* pyr, const float* coords, const float* wpk, const float* bias, float* c1, int64_t c1_bs,
+                         int B, int H, int W, int num_levels, int radius, hipStream_t stream) {
+    NND_REQUIRE(num_levels >= 1 && num_levels < MAX_LEVELS && num_levels * (2 * radius + 1) <= 64,
+                "lookup_convc1: %d levels x %d taps not supported", num_levels, 2 * radius + 1);
+    LookupArgs a;
+    make_layout(B, H, W, num_levels + 1, &a.L, nullptr);
+    a.B = B; a.H = H; a.W = W; a.num_levels = num_levels; a.radius = radius;
+    a.lay = make_lay(H, W, true);
+    NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
+    const int tiles_x = cdiv(W, 8);
+    hipLaunchKernelGGL(lookup_convc1_kernel, dim3(tiles_x * cdiv(H, 4), 1, B), dim3(512), 0, stream, pyr, coords, wpk, bias, c1,
+                       (long)c1_bs, a, tiles_x);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
 int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
                            hipStream_t stream, bool tiled) {
     const Lay lay = make_lay(H, W, tiled);

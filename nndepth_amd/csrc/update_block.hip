@@ -757,8 +757,14 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, sa));
             NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, sa));
             if (!no_a) NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
-            NND_TRY(lookup(s, it));
-            NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
+            const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;  // read per call: the parity test toggles it
+            if (!cre && !igev && !no_fuse_lk && p.d.cor_planes <= 64) {  // lookup + convc1 in one kernel, corr never stored
+                NND_TRY(lookup_convc1_launch(pyramid, w.coords, packed + p.L[C_C1].w_off, packed + p.L[C_C1].b_off, w.c1,
+                                             256 * n, B, H, W, num_levels, radius, s));
+            } else {
+                NND_TRY(lookup(s, it));
+                NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
+            }
             NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
             if (!no_a) NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
             NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));

@@ -554,3 +554,21 @@ def test_encoder_fullsize_vs_oracle_and_pytorch_path(raft_sd, tartanair_frames, 
     e_pt = (torch.cat([b1, b2]).cpu() - exp).abs().max().item()
     print(f"\nencoder 544x960: HIP vs oracle {e_hip:.2e}, PyTorch-ROCm (MIOpen) vs oracle {e_pt:.2e}, cnet HIP vs PyTorch {(ac - bc).abs().max().item():.2e}")
     assert e_hip <= 5e-5
+
+
+def test_fused_lookup_convc1_matches_unfused(raft_sd, monkeypatch):
+    """The loop's fused lookup + convc1 kernel against lookup -> conv_mfma(convc1).  Same arithmetic; the accumulation
+    order is identical when conv_mfma runs convc1 without split-K (the 544x960 configuration), otherwise the two
+    K-halves are summed separately there: whole-forward outputs agree to rounding."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    m = BaseRAFTStereo(iters=5, context_dim=64)
+    m.load_state_dict(raft_sd)
+    m = m.to(DEV).eval()
+    f1, f2 = weightgen.synthetic_frames(2, 2, 104, 168)  # 13 x 21 at 1/8: ragged tiles
+    a = m(f1.to(DEV), f2.to(DEV))
+    monkeypatch.setenv("NND_NO_FUSED_LOOKUP", "1")
+    b = m(f1.to(DEV), f2.to(DEV))
+    errs = [(x["up_disp"] - y["up_disp"]).abs().max().item() for x, y in zip(a, b)]
+    print("\nfused lookup+convc1 vs unfused:", " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) <= 2e-5
