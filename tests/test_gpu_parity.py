@@ -572,3 +572,20 @@ def test_fused_lookup_convc1_matches_unfused(raft_sd, monkeypatch):
     errs = [(x["up_disp"] - y["up_disp"]).abs().max().item() for x, y in zip(a, b)]
     print("\nfused lookup+convc1 vs unfused:", " ".join(f"{e:.1e}" for e in errs))
     assert max(errs) <= 2e-5
+
+
+def test_cre_cascade_midsize_vs_oracle(cre_sd, CR):
+    """CREStereo cascade at 384x640, 8 iterations (4 + 4 + 8 update steps over three scales, cross attention included)
+    against the CPU oracle on the same seeded frames: every one of the 16 outputs."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cre_stereo import CREStereoBase
+    fr1, fr2 = weightgen.synthetic_frames(5, 1, 384, 640)
+    m = CREStereoBase(iters=8)
+    m.load_state_dict(cre_sd, strict=True)
+    m = m.to(DEV).eval()
+    outs = m(fr1.to(DEV), fr2.to(DEV))
+    exp = CR.cre_stereo_forward(cre_sd, fr1, fr2, 8)
+    assert len(outs) == len(exp) == 16
+    errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
+    print("\ncre 384x640 it8 max-abs per output:", " ".join(f"{e:.1e}" for e in errs), f"(|flow| max {exp[-1].abs().max():.1f})")
+    assert max(errs) <= 1e-4
