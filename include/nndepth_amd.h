@@ -99,6 +99,11 @@ int nnd_agcl_corr_iter(const float* fmap1, const float* fmap2, const float* flow
 int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* flow, const float* extra_offset, float* out,
                          int N, int C, int H, int W, int small_patch, void* stream);
 
+/* IGEV initial disparity: regress_disparity(softmax over the candidate axis)
+ *   nndepth/models/igev_stereo/model.py:92-95,145-146
+ * logits (B,D,H,W) = the squeezed geometry volume -> out (B,1,H,W) = -sum_d d * softmax_d(logits).              */
+int nnd_softargmin_disparity(const float* logits, float* out, int B, int D, int H, int W, void* stream);
+
 /* ----------------------------------------------------------------------- convex upsample
  * Replaces RAFTStereo.convex_upsample  nndepth/models/raft_stereo/model.py:93-105
  * (IGEV copy igev_stereo/model.py:103-115; 2-channel CRE copy cre_stereo/model.py:110-122)

@@ -445,7 +445,33 @@ int igev_lookup_launch(const float* feat_pyramid, const float* geo_pyramid, cons
 }
 }  // namespace nnd
 
+// IGEV initial disparity (igev_stereo/model.py:92-95,145-146): out[b,0,h,w] = -sum_d d * softmax_d(logits[b,d,h,w]).
+// One thread per pixel, three passes over the D candidates (max, sum of exp, expectation); consecutive lanes are
+// consecutive pixels, so every pass reads coalesced rows of the (B,D,H,W) volume.
+__global__ void __launch_bounds__(256) softargmin_kernel(const float* __restrict__ logits, float* __restrict__ out, int D,
+                                                         long HW, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long b = idx / HW, p = idx - b * HW;
+    const float* x = logits + b * D * HW + p;
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, x[(long)d * HW]);
+    float sum = 0.f;
+    for (int d = 0; d < D; ++d) sum += expf(x[(long)d * HW] - mx);
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += (float)d * (expf(x[(long)d * HW] - mx) / sum);
+    out[idx] = -acc;
+}
+
 extern "C" {
+int nnd_softargmin_disparity(const float* logits, float* out, int B, int D, int H, int W, void* stream) {
+    NND_REQUIRE(logits && out && B > 0 && D > 0 && H > 0 && W > 0, "softargmin_disparity: bad argument");
+    const long HW = (long)H * W, total = (long)B * HW;
+    hipLaunchKernelGGL(softargmin_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, out, D, HW, total);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
 int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
                     int W, int num_levels, int radius, void* stream) {
     return igev_lookup_launch(feat_pyramid, geo_pyramid, coords, out, B, G, H, W, num_levels, radius, (hipStream_t)stream, false);

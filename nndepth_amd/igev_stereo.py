@@ -1,0 +1,207 @@
+"""IGEV-Stereo with the MI355X-native hot path.
+
+`IGEVStereoBase` keeps the reference's constructor kwargs, attribute / `state_dict()` names and
+`forward(frame1, frame2) -> List[{"up_disp": (B,1,H,W)}]` of nndepth/models/igev_stereo/model.py:15-158, including its
+two hooks for subclasses (`_init_fnet`, `_init_cost_volume_filter`, `forward_fnet`).  Inside `forward()`:
+
+    backbone (`forward_fnet`)                       whatever the subclass provides (PyTorch)
+    group-wise correlation volume + pyramids        HIP  csrc/corr1d.hip (GeometryAwareCostVolume)     model.py:133-141
+    3-D regulariser (Conv3d hourglass)              PyTorch-ROCm, `CostVolumeFilterNetwork` below
+    cv_squeezer Conv3d                              PyTorch-ROCm
+    soft-argmin initial disparity                   HIP  nnd_softargmin_disparity                        model.py:145-146
+    for iters: combined lookup -> update block -> coords += delta -> convex upsample (absolute coords, Q5)
+                                                    HIP, ONE C-ABI call: nnd_igev_stereo_refine          model.py:152-158
+
+`IGEVStereoMBNet` (MobileNetV3 backbone from timm) is declared for interface parity; timm is an external dependency of
+the reference that is not part of this repository.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .blocks import BasicUpdateBlock
+from .cost_volume import GeometryAwareCostVolume
+from .raft_stereo import load_weights
+from .upsample import convex_upsample
+
+
+# ------------------------------------------------------------------ a15: 3-D regulariser (stays on PyTorch-ROCm)
+def _cbr3d(cin: int, cout: int, stride: int) -> nn.Module:
+    """Conv3d(bias=False) + BatchNorm3d + LeakyReLU(0.01), parameter names conv / bn as in the reference's ConvBn3D
+    (nndepth/models/igev_stereo/cost_volume.py:101-115)."""
+    m = nn.Module()
+    m.conv = nn.Conv3d(cin, cout, 3, stride, 1, bias=False)
+    m.bn = nn.BatchNorm3d(cout)
+    m.relu = nn.LeakyReLU()
+    return m
+
+
+def _run_cbr(m: nn.Module, x: torch.Tensor, upsample: bool = False) -> torch.Tensor:
+    if upsample:  # Upsampler3D (cost_volume.py:118-130): trilinear x2, align_corners=True, then conv-bn-act
+        x = F.interpolate(x, scale_factor=2.0, mode="trilinear", align_corners=True)
+    return m.relu(m.bn(m.conv(x)))
+
+
+class _Gate(nn.Module):
+    """FeatureGuidedBlock (cost_volume.py:133-147): sigmoid(1x1 conv stack of the guide map) scales every candidate."""
+
+    def __init__(self, cv_channel: int, feat_channel: int):
+        super().__init__()
+        self.feat_att = nn.Sequential(nn.Conv2d(feat_channel, feat_channel // 2, 1), nn.BatchNorm2d(feat_channel // 2),
+                                      nn.ReLU(False), nn.Conv2d(feat_channel // 2, cv_channel, 1))
+
+    def forward(self, cv: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
+        return torch.sigmoid(self.feat_att(feat).unsqueeze(2)) * cv
+
+
+class CostVolumeFilterNetwork(nn.Module):
+    """3-level Conv3d hourglass with feature gating (cost_volume.py:150-210); same parameter names."""
+
+    def __init__(self, in_channels: int, feat_channels: List[int]):
+        super().__init__()
+        c = in_channels
+        for i, (ci, co) in enumerate(((c, 2 * c), (2 * c, 4 * c), (4 * c, 8 * c)), start=1):
+            seq = nn.Sequential(_cbr3d(ci, co, 2), _cbr3d(co, co, 1))
+            setattr(self, f"conv{i}", seq)
+            setattr(self, f"conv{i}_feat_guided", _Gate(co, feat_channels[i - 1]))
+        self.conv3_up = _cbr3d(8 * c, 4 * c, 1)
+        self.proj_3 = _cbr3d(8 * c, 4 * c, 1)
+        self.conv3_up_feat_guided = _Gate(4 * c, feat_channels[1])
+        self.conv2_up = _cbr3d(4 * c, 2 * c, 1)
+        self.proj_2 = _cbr3d(4 * c, 2 * c, 1)
+        self.conv2_up_feat_guided = _Gate(2 * c, feat_channels[0])
+        self.conv1_up = _cbr3d(2 * c, c, 1)
+        self.final_conv = _cbr3d(c, c, 1)
+
+    def forward(self, x: torch.Tensor, features: List[torch.Tensor]) -> torch.Tensor:
+        def down(seq, t):
+            return _run_cbr(seq[1], _run_cbr(seq[0], t))
+        c1 = self.conv1_feat_guided(down(self.conv1, x), features[0])
+        c2 = self.conv2_feat_guided(down(self.conv2, c1), features[1])
+        c3 = self.conv3_feat_guided(down(self.conv3, c2), features[2])
+        c2 = _run_cbr(self.proj_3, torch.cat((_run_cbr(self.conv3_up, c3, True), c2), dim=1))
+        c2 = self.conv3_up_feat_guided(c2, features[1])
+        c1 = _run_cbr(self.proj_2, torch.cat((_run_cbr(self.conv2_up, c2, True), c1), dim=1))
+        c1 = self.conv2_up_feat_guided(c1, features[0])
+        return _run_cbr(self.final_conv, _run_cbr(self.conv1_up, c1, True))
+
+
+# ------------------------------------------------------------------ the model
+class IGEVStereoBase(nn.Module):
+    def __init__(self, update_cls: str = "basic_update_block", cv_groups: int = 8, iters: int = 12, hidden_dim: int = 128,
+                 context_dim: int = 128, corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
+                 include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
+                 fused_loop: bool = True):
+        super().__init__()
+        if update_cls != "basic_update_block":
+            raise KeyError(update_cls)
+        self.fnet = self._init_fnet()
+        self.iters, self.hidden_dim, self.context_dim = iters, hidden_dim, context_dim
+        self.cv_groups, self.corr_levels, self.corr_radius = cv_groups, corr_levels, corr_radius
+        self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, context_dim=context_dim, flow_channel=1,
+                                             cor_planes=corr_levels * (2 * corr_radius + 1) * cv_groups * 2, spatial_scale=4)
+        self.cv_regularizer = self._init_cost_volume_filter()
+        self.corr_fn = GeometryAwareCostVolume
+        self.cv_squeezer = nn.Conv3d(cv_groups, 1, 3, 1, 1)
+        self.tracing, self.include_preprocessing = tracing, include_preprocessing
+        self.weights, self.strict_load = weights, strict_load
+        self.fused_loop = fused_loop
+
+    def _init_fnet(self):
+        raise NotImplementedError("Must be implemented in child class")
+
+    def _init_cost_volume_filter(self):
+        raise NotImplementedError("Must be implemented in child class")
+
+    def forward_fnet(self, frame1: torch.Tensor, frame2: torch.Tensor):
+        """Must return fmap1, fmap2, cnet1 and guide_features."""
+        raise NotImplementedError("Must be implemented in child class")
+
+    def regress_disparity(self, distribution: torch.Tensor, width: int) -> torch.Tensor:
+        disp = torch.arange(0, width, dtype=distribution.dtype, device=distribution.device).reshape(1, -1, 1, 1)
+        return -torch.sum(disp * distribution, dim=1, keepdim=True)
+
+    def initialize_coords(self, fmap1):
+        B, _, H, W = fmap1.shape
+        return torch.arange(W, device=fmap1.device).float()[None, None, None, :].repeat(B, 1, H, 1)
+
+    def convex_upsample(self, flow, mask, rate=4):
+        return convex_upsample(flow, mask, rate)
+
+    @torch.no_grad()
+    def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
+        fmap1, fmap2, cnet1, guide_features = self.forward_fnet(frame1, frame2)
+        fnet_ds = frame1.shape[-1] // fmap1.shape[-1]
+        fmap1, fmap2 = fmap1.float(), fmap2.float()
+        net, inp = torch.split(cnet1, cnet1.shape[1] // 2, dim=1)
+        net, inp = torch.tanh(net), F.relu(inp)
+        corr = self.corr_fn(fmap1, fmap2, guide_features, self.cv_regularizer, self.corr_levels, self.corr_radius,
+                            self.cv_groups)
+        B, _, H1, W1 = fmap1.shape
+        W2 = fmap2.shape[-1]
+        geo = corr.geo_aware_cv[0].reshape(B, self.cv_groups, H1, W1, W2).permute(0, 1, 4, 2, 3)
+        logits = self.cv_squeezer(geo).squeeze(1)  # (B, W2, H1, W1)
+        if logits.is_cuda:
+            init = ops.softargmin_disparity(logits.float())
+        else:
+            init = self.regress_disparity(F.softmax(logits, dim=1), W1)
+        if self.fused_loop and isinstance(corr, GeometryAwareCostVolume):
+            eng = self.update_block.sync_engine(frame1.device)
+            up, _, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,
+                                       net.float(), inp.float(), fnet_ds, self.iters, disp_init=init, keep_all=True)
+            return [{"up_disp": up[i]} for i in range(self.iters)]
+        coords1 = self.initialize_coords(fmap1) + init
+        outs = []
+        for _ in range(self.iters):
+            net, mask, delta = self.update_block(net, inp, corr(coords1), coords1)
+            coords1 = coords1 + delta
+            outs.append({"up_disp": self.convex_upsample(coords1, mask, rate=fnet_ds)})
+        return outs
+
+
+class IGEVStereoMBNet(IGEVStereoBase):
+    """IGEV-Stereo with the timm MobileNetV3-Large backbone (nndepth/models/igev_stereo/model.py:163-203)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.fnet_proj = nn.Sequential(nn.Conv2d(24, self.hidden_dim * 2, 3, 1, 1), nn.ReLU(False))
+        self.cnet_proj = nn.Sequential(nn.Conv2d(24, self.context_dim * 2, 3, 1, 1), nn.ReLU(False))
+        if self.weights is not None:
+            load_weights(self, self.weights, self.strict_load)
+
+    def _init_fnet(self):
+        try:
+            from timm.models.mobilenetv3 import tf_mobilenetv3_large_100
+        except ImportError as e:  # the reference pins timm==1.0.16 (docker/requirements.txt); not vendored here
+            raise ImportError("IGEVStereoMBNet needs timm's tf_mobilenetv3_large_100 backbone") from e
+
+        class _MobilenetV3LargeEncoder(nn.Module):  # nndepth/encoders/mobilenetv3_encoder.py: stages 1-5 are hooked
+            def __init__(self):
+                super().__init__()
+                self.backbone = tf_mobilenetv3_large_100(pretrained=True, features_only=True)
+
+            def forward(self, x):
+                bb = self.backbone
+                x = bb.act1(bb.bn1(bb.conv_stem(x)))
+                feats = []
+                for i, blk in enumerate(bb.blocks):
+                    x = blk(x)
+                    if i in (1, 2, 3, 4, 5):
+                        feats.append(x)
+                return feats
+
+        return _MobilenetV3LargeEncoder()
+
+    def _init_cost_volume_filter(self):
+        return CostVolumeFilterNetwork(self.cv_groups, [40, 80, 160])
+
+    def forward_fnet(self, frame1: torch.Tensor, frame2: torch.Tensor):
+        B = frame1.shape[0]
+        feats = self.fnet(torch.cat([frame1, frame2], dim=0))
+        fmaps = feats[0]
+        cnet1 = self.cnet_proj(fmaps[:B].clone())
+        fmap1, fmap2 = torch.split(self.fnet_proj(fmaps), B, dim=0)
+        return fmap1, fmap2, cnet1, [feats[i][:B] for i in (1, 2, 4)]

@@ -492,3 +492,14 @@ class EncoderEngine:
             check(lib.nnd_encoder_forward(C.byref(self.desc), _p(self.packed), _p(frames), _p(fmap), _p(cnet), n_cnet,
                                           _p(self._ws), N, H, W, _stream(d)), "encoder_forward")
         return fmap, cnet
+
+
+def softargmin_disparity(logits: torch.Tensor) -> torch.Tensor:
+    """IGEV initial disparity: logits (B,D,H,W) -> -sum_d d * softmax_d (B,1,H,W) (igev_stereo/model.py:92-95,145-146)."""
+    d = _dev(logits)
+    logits = logits.contiguous()
+    B, D, H, W = logits.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_softargmin_disparity(_p(logits), _p(out), B, D, H, W, _stream(d)), "softargmin_disparity")
+    return out

@@ -224,6 +224,14 @@ def igev_refine(sd: SD, p: str, fp, gp, net, inp, init_disp, iters: int, num_gro
     return ups
 
 
+def igev_init_disparity(logits: torch.Tensor) -> torch.Tensor:
+    """nndepth/models/igev_stereo/model.py:92-95,145-146: logits (B,D,H,W) = squeezed geometry volume ->
+    -sum_d d * softmax_d(logits), (B,1,H,W)."""
+    dist = F.softmax(logits, dim=1)
+    disp = torch.arange(0, logits.shape[1], dtype=dist.dtype).reshape(1, -1, 1, 1)
+    return -torch.sum(disp * dist, dim=1, keepdim=True)
+
+
 def epe(disp_gt: torch.Tensor, disp_pred: torch.Tensor, max_flow: float = 1000.0) -> float:
     """nndepth/models/raft_stereo/scripts/evaluate.py:62-83 for equal-size inputs."""
     e = torch.sum((disp_pred - disp_gt) ** 2, dim=1).sqrt()

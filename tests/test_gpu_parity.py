@@ -589,3 +589,33 @@ def test_cre_cascade_midsize_vs_oracle(cre_sd, CR):
     errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
     print("\ncre 384x640 it8 max-abs per output:", " ".join(f"{e:.1e}" for e in errs), f"(|flow| max {exp[-1].abs().max():.1f})")
     assert max(errs) <= 1e-4
+
+
+# ------------------------------------------------------------ IGEV model (a15 in PyTorch, a16 init + loop in HIP)
+def test_igev_softargmin_vs_oracle(ops, R):
+    torch.manual_seed(12)
+    for (B, D, H, W, amp) in ((2, 60, 17, 60, 8.0), (1, 240, 9, 33, 30.0), (1, 7, 3, 5, 0.1)):
+        logits = torch.randn(B, D, H, W) * amp
+        exp = R.igev_init_disparity(logits)
+        got = ops.softargmin_disparity(logits.to(DEV)).cpu()
+        assert (got - exp).abs().max() <= 2e-5 * D, (B, D, H, W)
+
+
+def test_igev_forward_golden(gold):
+    """Whole IGEVStereoBase.forward (HIP volume + pyramids, PyTorch regulariser, HIP soft-argmin init, fused HIP loop with
+    absolute coordinates) against the reference's forward on the same tiny backbone and weights."""
+    from igev_double import make_igev
+    from nndepth_amd import weightgen
+    from nndepth_amd.igev_stereo import IGEVStereoBase, CostVolumeFilterNetwork
+    g = gold("igev_forward.npz")
+    m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=4, hidden_dim=64, context_dim=64)
+    weightgen.fill_module_(m, "igev.")
+    m = m.to(DEV).eval()
+    f1, f2 = weightgen.synthetic_frames(6, 1, 128, 192)
+    outs = m(f1.to(DEV), f2.to(DEV))
+    errs = [np.abs(o["up_disp"].cpu().numpy() - g["up_disp"][i]).max() for i, o in enumerate(outs)]
+    print("\nigev forward max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs), f"(|coords| max {np.abs(g['up_disp'][-1]).max():.1f})")
+    assert len(outs) == 4 and max(errs) <= 1e-4
+    m.fused_loop = False
+    seam = m(f1.to(DEV), f2.to(DEV))
+    assert max((a["up_disp"] - b["up_disp"]).abs().max().item() for a, b in zip(outs, seam)) <= 5e-5

@@ -93,3 +93,15 @@ def test_igev_volume_oracle(gold, name, B, H, W):
     out = R.igev_lookup(fp, gp, coords, 8, 4, 4)
     assert tuple(out.shape) == (B, 576, H, W)
     assert np.array_equal(out.numpy(), g[name + "_out"])
+
+
+def test_igev_model_keys_and_init_disparity(gold):
+    """a15/a16: the drop-in IGEVStereoBase + CostVolumeFilterNetwork register exactly the reference's state_dict keys
+    (captured from the reference's IGEVStereoBase on the same tiny backbone), and the oracle's soft-argmin
+    reproduces the reference's regress_disparity(softmax(.)) bit for bit."""
+    from igev_double import make_igev
+    from nndepth_amd.igev_stereo import IGEVStereoBase, CostVolumeFilterNetwork
+    g = gold("igev_forward.npz")
+    m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=4, hidden_dim=64, context_dim=64)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert np.array_equal(R.igev_init_disparity(t(g["logits"])).numpy(), g["init"])
