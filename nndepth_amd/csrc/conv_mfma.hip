@@ -114,7 +114,8 @@ __device__ __forceinline__ float tanhf_(float v) {
 
 // NE: patch elements staged per thread per super-chunk (the thread owns one patch position and NE channels)
 template <int KH, int KW, int CI_T, int P, int NE, int STR = 1>
-__global__ void __launch_bounds__((P == 1 ? 768 : 512)) conv_mfma_kernel(ConvArgs a) {
+__global__ void __launch_bounds__((P == 1 ? 768 : 512)) __attribute__((amdgpu_waves_per_eu((P == 1 && NE == 8 ? 4 : 1))))
+conv_mfma_kernel(ConvArgs a) {
     constexpr int NT = KH * KW;
     constexpr int SG = CI_T < 32 ? CI_T : 32;  // channels per pipeline step
     constexpr int NGRP = CI_T / SG;            // channel groups per tap
@@ -444,7 +445,7 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
     if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &force_p, &force_ks, &force_wco);
     double best = 1e30;
     bool found = false;
-    for (int ks : {1, 2})
+    for (int ks : {1, 2})  // ks = 4 measured slower on every layer (scripts/sweep_conv.py)
     for (int wco : {8, 6, 4, 3, 2, 1}) {
         if (force_ks > 0 && ks != force_ks) continue;
         if (force_wco > 0 && wco != force_wco) continue;

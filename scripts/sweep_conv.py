@@ -13,7 +13,7 @@ ub = ub.to("cuda:0")
 eng = ub.sync_engine("cuda:0")
 ws = eng.workspace(B, H, W, "cuda:0"); ws.normal_()
 names = eng.conv_names()
-cfgs = [(p, k, w) for p in (1, 2) for k in (1, 2) for w in (1, 2, 3, 4, 6, 8) if k * w <= (12 if p == 1 else 8)]
+cfgs = [(p, k, w) for p in (1, 2) for k in (1, 2, 4) for w in (1, 2, 3, 4, 6, 8) if k * w <= (12 if p == 1 else 8)]
 for i, nm in enumerate(names):
     res = []
     for (p, k, w) in cfgs:
