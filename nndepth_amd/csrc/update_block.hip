@@ -99,7 +99,7 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
 
 // ------------------------------------------------------------------------------- workspace
 struct Bufs {
-    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow, *hcopy, *ctxb;
+    float *c1, *cf, *f1, *hx, *z, *rh, *fm, *corr, *mask, *delta, *coords, *flow, *ctxb;
     int64_t total;
 };
 
@@ -124,7 +124,6 @@ static void carve(const Plan& p, int B, int H, int W, float* base, Bufs* b) {
     b->delta = take(fc);
     b->coords = take(1);
     b->flow = take(fc);
-    b->hcopy = take(2 * hid);  // double-buffered copy of h for the mask branch (side stream)
     b->ctxb = take(6 * hid);   // context terms of the GRU convs: [zr1 2h | q1 h | zr2 2h | q2 h]
     b->total = off;
 }
@@ -169,23 +168,6 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
         acc += bias[co];
         if (ok) out[b * obs + co * HW + pix_off(lay, y, x)] = fmaxf(acc, 0.f);
     }
-}
-
-// coords += delta; flow = coords - x  (model.py:134-135), mirrored into the GRU input buffer.
-__global__ void advance_kernel(float* __restrict__ coords, const float* __restrict__ delta, float* __restrict__ flow,
-                               float* __restrict__ hx_flow, long hx_bs, int B, int H, int W, int absolute, Lay lay) {
-    const long HW = (long)H * W;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * HW) return;
-    const int b = (int)(idx / HW);
-    const long pix = idx % HW;
-    const int x = (int)(pix % W);
-    const long o = b * lay.plane + pix_off(lay, (int)(pix / W), x);
-    float cnew = coords[o] + delta[o];
-    float f = absolute ? cnew : cnew - (float)x;
-    coords[o] = cnew;
-    flow[o] = f;
-    hx_flow[b * hx_bs + (o - b * lay.plane)] = f;
 }
 
 // coords = x (+ disp_init); flow = coords - x
@@ -309,14 +291,7 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
 static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
 
 // IO of conv `id` given the workspace; `corr` / `flow_src` are the external inputs.
-struct IoOpt {
-    int parity = -1;       // >= 0: last GRU q also writes hcopy[parity]; mask.0 reads it
-    bool advance = false;  // flow_head.conv2 runs the fused coords/flow update
-    bool absolute = false; // ... and emits the coordinate itself as `flow` (IGEV)
-};
-
-static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*H*W*/, float* mask_dst, float* delta_dst,
-                      IoOpt opt = IoOpt()) {
+static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*plane*/, float* mask_dst, float* delta_dst) {
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels;
     const int hxC = 2 * hid + ctx;
     ConvIO io{};
@@ -340,7 +315,6 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.out0 = act(w.hx, hxC * n, hid);
             io.aux0 = act(w.hx, hxC * n, hid);
             io.aux1 = act(w.z, hid * n, hid);
-            if (opt.parity >= 0 && id == (p.sep ? C_Q2 : C_Q1)) io.out1 = act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid);
             break;
         case C_ZR1X:
         case C_ZR2X: {  // [h | motion+flow] + context bias map
@@ -361,7 +335,6 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.aux0 = act(w.hx, hxC * n, hid);
             io.aux1 = act(w.z, hid * n, hid);
             io.bmap = act(w.ctxb + (id == C_Q1X ? 2 * hid : 5 * hid) * n, 6 * hid * n, hid);
-            if (opt.parity >= 0 && id == (p.sep ? C_Q2X : C_Q1X)) io.out1 = act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid);
             break;
         case C_ZR1C:
         case C_ZR2C:  // context term: conv over `inp` only (+ the conv's bias), linear
@@ -375,7 +348,7 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             break;
         case C_FH1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, hid); break;
         case C_M0:
-            io.src0 = opt.parity >= 0 ? act(w.hcopy + (int64_t)opt.parity * hid * n, 2 * hid * n, hid) : act(w.hx, hxC * n, hid);
+            io.src0 = act(w.hx, hxC * n, hid);
             io.out0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
             break;
         case C_M2:
@@ -388,7 +361,7 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
     return io;
 }
 
-static int conv_epi(int id, IoOpt opt = IoOpt()) {
+static int conv_epi(int id) {
     switch (id) {
         case C_ZR1: case C_ZR2: case C_ZR1X: case C_ZR2X: return EPI_GRU_ZR;
         case C_Q1: case C_Q2: case C_Q1X: case C_Q2X: return EPI_GRU_Q;
@@ -411,9 +384,9 @@ static int debug_sync(const char* what, hipStream_t s) {
 }
 
 static int run_conv(const Plan& p, const float* blob, const Bufs& w, int id, Act corr, float* mask_dst, float* delta_dst,
-                    int B, int H, int W, hipStream_t s, IoOpt opt = IoOpt()) {
-    ConvIO io = conv_io(p, w, id, corr, tiled_plane(H, W), mask_dst, delta_dst, opt);
-    int rc = launch_conv(p.L[id], blob, io, conv_epi(id, opt), B, H, W, s);
+                    int B, int H, int W, hipStream_t s) {
+    ConvIO io = conv_io(p, w, id, corr, tiled_plane(H, W), mask_dst, delta_dst);
+    int rc = launch_conv(p.L[id], blob, io, conv_epi(id), B, H, W, s);
     if (rc != NND_OK) return rc;
     return debug_sync(kConvNames[id], s);
 }
@@ -457,8 +430,8 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
 // Side streams + events for the fused loop.  Created once per device on first use (the only mutable global
 // state of the library); all cross-stream edges are explicit events, the caller's stream is joined at the end.
 struct Streams {
-    hipStream_t a = nullptr, b = nullptr;  // a: flow branch, b: mask/upsample branch
-    hipEvent_t f2 = nullptr, q2 = nullptr, adv = nullptr, up = nullptr;
+    hipStream_t a = nullptr;            // flow branch of the motion encoder (convf1, convf2)
+    hipEvent_t f2 = nullptr, adv = nullptr;
     bool ok = false;
 };
 static Streams* side_streams() {
@@ -469,14 +442,11 @@ static Streams* side_streams() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     Streams& s = st[dev];
     if (!s.ok) {
-        // lowest priority: the side branches only fill the bubbles of the recurrence on the caller's stream
+        // lowest priority: the side branch only fills the bubbles of the recurrence on the caller's stream
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-        static const bool flat = getenv("NND_FLAT_PRIORITY") != nullptr;
-        if (flat) least = 0;
         if (hipStreamCreateWithPriority(&s.a, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithPriority(&s.b, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-        for (hipEvent_t* e : {&s.f2, &s.q2, &s.adv, &s.up})
+        for (hipEvent_t* e : {&s.f2, &s.adv})
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
         s.ok = true;
     }
@@ -525,11 +495,6 @@ static int from_tiled(const float* src, int64_t sbs, float* dst, int B, int C, i
     return NND_OK;
 }
 
-static int copy_slice(float* dst, int64_t dbs, const float* src, int64_t sbs, int64_t floats, int B, hipStream_t s) {
-    NND_HIP_CHECK(hipMemcpy2DAsync(dst, dbs * sizeof(float), src, sbs * sizeof(float), floats * sizeof(float), B,
-                                   hipMemcpyDeviceToDevice, s));
-    return NND_OK;
-}
 
 }  // namespace nnd
 
@@ -721,87 +686,57 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     // per-pair context terms of the GRU convs (inp is constant over the iterations)
     for (int id : {(int)C_ZR1C, (int)C_Q1C, (int)C_ZR2C, (int)C_Q2C})
         if (p.sep || id < C_ZR2C) NND_TRY(run_conv(p, packed, w, id, c, nullptr, nullptr, B, H, W, s));
-    static const bool single = getenv("NND_SINGLE_STREAM") != nullptr;
-    Streams* st = single ? nullptr : side_streams();
-    if (!st) {  // plain in-order version (also the debugging reference for the DAG below)
-        for (int it = 0; it < iters; ++it) {
-            NND_REQUIRE(!cre, "cre_stereo_refine: NND_SINGLE_STREAM debugging path is RAFT/IGEV only");
+    // Per-iteration schedule over two streams (M = caller's stream carries the recurrence):
+    //   M: lookup (+convc1), convc2, [f2] conv, zr1, q1, zr2, q2, flow_head.conv1, flow_head.conv2+advance ->(adv),
+    //      mask.0, mask.2 + convex upsample (fused)
+    //   A: (adv) convf1, convf2 ->(f2)                              flow branch of the motion encoder
+    // Measured on MI355X at 544x960 (ms per pair): M+A 17.6 | M+A+B (mask branch on a third stream, which needs a
+    // double-buffered copy of h and 3 more event operations on M per iteration) 18.0 | everything on M 17.7 | M only,
+    // captured into a hipGraph 17.6 | the 3-stream DAG as a hipGraph 34.  The kernels of one iteration already fill the
+    // chip (sum of the stand-alone kernel times = in-loop time), so more streams buy no overlap and every event
+    // record / wait on M costs a ~7 us bubble.
+    Streams* st = side_streams();
+    NND_REQUIRE(st, "refine: could not create the side stream");
+    const bool no_fuse_up = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;  // read per call: the parity tests toggle these
+    const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;
+    const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
+    const bool fused_lk = !cre && !igev && !no_fuse_lk && p.d.cor_planes <= 64;
+    NND_HIP_CHECK(hipEventRecord(st->adv, s));
+    for (int it = 0; it < iters; ++it) {
+        NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
+        NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, st->a));
+        NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
+        NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
+        if (fused_lk) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
+            NND_TRY(lookup_convc1_launch(pyramid, w.coords, packed + p.L[C_C1].w_off, packed + p.L[C_C1].b_off, w.c1, 256 * n, B,
+                                         H, W, num_levels, radius, s));
+        } else {
             NND_TRY(lookup(s, it));
-            NND_TRY(run_update(p, packed, w, c, w.flow, w.mask, w.delta, B, H, W, s));
-            hipLaunchKernelGGL(advance_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.delta, w.flow, hx_flow, (long)(hxC * n), B, H, W,
-                               igev ? 1 : 0, lay);
-            NND_LAUNCH_CHECK();
-            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, 1, H, W, rate, s, true));
+            NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
         }
-    } else {
-        // Per-iteration DAG over two streams (M = caller's stream carries the recurrence):
-        //   M: lookup, convc1, convc2, [f2] conv, zr1, q1, zr2, q2, flow_head.conv1, flow_head.conv2+advance ->(adv),
-        //      mask.0, mask.2 + convex upsample (fused)
-        //   A: (adv) convf1, convf2 ->(f2)                              flow branch of the motion encoder
-        // Measured on MI355X at 544x960 (ms per pair): M+A 17.17 | M+A+B (mask branch on a third stream, needs a
-        // double-buffered copy of h and 3 more event operations on M per iteration) 17.97 | everything on M 17.68 |
-        // M only, captured into a hipGraph 17.64.  The kernels of one iteration already fill the chip (the sum of the
-        // stand-alone kernel times equals the in-loop time), so a third stream buys no overlap and each event
-        // record / wait on M costs a ~7 us bubble.  NND_STREAM_B=1 / NND_NO_STREAM_A=1 select the other schedules.
-        static const bool no_fuse = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;
-        const bool fused_up = !no_fuse && mask_upsample_supported(rate, 2 * hid, fc);
-        NND_HIP_CHECK(hipEventRecord(st->adv, s));
-        for (int it = 0; it < iters; ++it) {
-            IoOpt opt;
-            opt.parity = getenv("NND_STREAM_B") ? (it & 1) : -1;  // the h copy is only needed when mask.0 runs on stream B
-            opt.advance = true;
-            opt.absolute = igev;
-            static const bool no_a = getenv("NND_NO_STREAM_A") != nullptr;  // measured: flow branch on M instead of A is 2.6 % slower
-            hipStream_t sa = no_a ? s : st->a;
-            if (!no_a) NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
-            NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, sa));
-            NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, sa));
-            if (!no_a) NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
-            const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;  // read per call: the parity test toggles it
-            if (!cre && !igev && !no_fuse_lk && p.d.cor_planes <= 64) {  // lookup + convc1 in one kernel, corr never stored
-                NND_TRY(lookup_convc1_launch(pyramid, w.coords, packed + p.L[C_C1].w_off, packed + p.L[C_C1].b_off, w.c1,
-                                             256 * n, B, H, W, num_levels, radius, s));
-            } else {
-                NND_TRY(lookup(s, it));
-                NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
-            }
-            NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
-            if (!no_a) NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
-            NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
-            NND_TRY(run_conv(p, packed, w, C_ZR1X, c, nullptr, nullptr, B, H, W, s));
-            NND_TRY(run_conv(p, packed, w, C_Q1X, c, nullptr, nullptr, B, H, W, s, opt));
-            if (p.sep) {
-                NND_TRY(run_conv(p, packed, w, C_ZR2X, c, nullptr, nullptr, B, H, W, s));
-                NND_TRY(run_conv(p, packed, w, C_Q2X, c, nullptr, nullptr, B, H, W, s, opt));
-            }
-            static const bool no_b = getenv("NND_STREAM_B") == nullptr;  // default: output branch on the main stream (see above)
-            hipStream_t sb = no_b ? s : st->b;
-            if (!no_b) {
-                NND_HIP_CHECK(hipEventRecord(st->q2, s));
-                NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->q2, 0));
-                NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, sb, opt));
-                if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, sb));
-            }
-            NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
-            if (it > 0 && !no_b) NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));
-            NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
-            NND_HIP_CHECK(hipEventRecord(st->adv, s));  // the flow is final: stream A may start the next flow branch
-            if (no_b) {
-                NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, sb, opt));
-                if (!fused_up) NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, sb));
-            } else {
-                NND_HIP_CHECK(hipStreamWaitEvent(st->b, st->adv, 0));
-            }
-            if (fused_up)  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
-                NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow,
-                                             up_out + (int64_t)it * up_iter_stride, B, H, W, rate, sb, true, fc));
-            else
-                NND_TRY(convex_upsample_launch(w.flow, w.mask, up_out + (int64_t)it * up_iter_stride, B, fc, H, W, rate, sb, true));
-            if (!no_b) NND_HIP_CHECK(hipEventRecord(st->up, st->b));
+        NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
+        NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
+        NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
+        NND_TRY(run_conv(p, packed, w, C_ZR1X, c, nullptr, nullptr, B, H, W, s));
+        NND_TRY(run_conv(p, packed, w, C_Q1X, c, nullptr, nullptr, B, H, W, s));
+        if (p.sep) {
+            NND_TRY(run_conv(p, packed, w, C_ZR2X, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(run_conv(p, packed, w, C_Q2X, c, nullptr, nullptr, B, H, W, s));
         }
-        NND_HIP_CHECK(hipStreamWaitEvent(s, st->up, 0));   // join B
-        if (!getenv("NND_NO_STREAM_A")) NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));   // join A (already consumed, keeps the contract simple)
+        NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
+        NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
+        NND_HIP_CHECK(hipEventRecord(st->adv, s));  // the flow is final: stream A may start the next flow branch
+        NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, s));
+        float* up_it = up_out + (int64_t)it * up_iter_stride;
+        if (fused_up) {  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
+            NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow, up_it, B, H, W, rate, s,
+                                         true, fc));
+        } else {
+            NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, s));
+            NND_TRY(convex_upsample_launch(w.flow, w.mask, up_it, B, fc, H, W, rate, s, true));
+        }
     }
+    NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));  // join A (its last result was consumed already; keeps the contract simple)
     if (low_out) NND_TRY(from_tiled(w.flow, fc * n, low_out, B, fc, H, W, s));
     if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
     return NND_OK;
@@ -849,86 +784,14 @@ int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B,
     return launch_conv(L, packed_dev, io, relu ? EPI_RELU : EPI_LINEAR, B, H, W, (hipStream_t)stream);
 }
 
-// hipGraph replay of the whole loop (opt-in, NND_GRAPH=1): the 3-stream DAG is captured once per distinct argument
-// set (pointers included) on an internal capture stream and replayed on the caller's stream.  Measured on MI355X /
-// ROCm 7.2: correct, but 34 ms vs 19.6 ms per pair for direct stream launches (the replay serialises the
-// branches), so it is off by default.
-struct RefineKey {
-    nnd_update_block_desc d;
-    const void* ptr[9];
-    int64_t stride;
-    int v[8];
-    bool operator==(const RefineKey& o) const { return memcmp(this, &o, sizeof(RefineKey)) == 0; }
-};
-struct RefineGraph {
-    RefineKey key;
-    hipGraphExec_t exec;
-    uint64_t stamp;
-};
-
 int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
                            int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
                            int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W,
                            int rate, int iters, void* stream) {
-    static const bool use_graph = getenv("NND_GRAPH") != nullptr && getenv("NND_DEBUG_SYNC") == nullptr &&
-                                  getenv("NND_SINGLE_STREAM") == nullptr;
-    if (!use_graph || !desc)
-        return enqueue_refine(desc, packed, pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
-                              net_out, workspace, B, H, W, rate, iters, stream);
-    static std::mutex mu;
-    static std::vector<RefineGraph> cache;
-    static hipStream_t cs = nullptr;
-    static uint64_t clock_ = 0;
-    std::lock_guard<std::mutex> lock(mu);
-    RefineKey key;
-    memset(&key, 0, sizeof(key));
-    key.d = *desc;
-    const void* ptrs[9] = {packed, pyramid, net, inp, disp_init, up_out, low_out, net_out, workspace};
-    memcpy(key.ptr, ptrs, sizeof(ptrs));
-    key.stride = up_iter_stride;
-    int vals[8] = {num_levels, radius, B, H, W, rate, iters, 0};
-    (void)hipGetDevice(&vals[7]);
-    memcpy(key.v, vals, sizeof(vals));
-    RefineGraph* hit = nullptr;
-    for (auto& g : cache)
-        if (g.key == key) hit = &g;
-    static const bool gverbose = getenv("NND_GRAPH_VERBOSE") != nullptr;
-    if (gverbose) fprintf(stderr, "[nnd] refine graph %s (cache %zu)\n", hit ? "hit" : "MISS", cache.size());
-    if (!hit) {
-        if (!cs) NND_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        NND_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_refine(desc, packed, pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
-                                net_out, workspace, B, H, W, rate, iters, cs);
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamEndCapture(cs, &graph);
-        if (rc != NND_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        if (e != hipSuccess || !graph) {
-            set_error("raft_stereo_refine: graph capture failed: %s", hipGetErrorString(e));
-            return NND_ERR_HIP;
-        }
-        hipGraphExec_t exec = nullptr;
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            set_error("raft_stereo_refine: graph instantiate failed: %s", hipGetErrorString(e));
-            return NND_ERR_HIP;
-        }
-        if (cache.size() >= 8) {  // evict the least recently used
-            size_t lru = 0;
-            for (size_t i = 1; i < cache.size(); ++i)
-                if (cache[i].stamp < cache[lru].stamp) lru = i;
-            (void)hipGraphExecDestroy(cache[lru].exec);
-            cache.erase(cache.begin() + lru);
-        }
-        cache.push_back(RefineGraph{key, exec, 0});
-        hit = &cache.back();
-    }
-    hit->stamp = ++clock_;
-    NND_HIP_CHECK(hipGraphLaunch(hit->exec, (hipStream_t)stream));
-    return NND_OK;
+    // (hipGraph replay of the loop was measured and dropped: no faster than direct launches for the linear schedule,
+    //  2x slower for a multi-stream DAG on ROCm 7.2 — see the schedule note in enqueue_refine.)
+    return enqueue_refine(desc, packed, pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
+                          net_out, workspace, B, H, W, rate, iters, stream);
 }
 
 int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* feat_pyramid,
