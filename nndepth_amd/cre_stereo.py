@@ -186,3 +186,15 @@ class CREStereoBase(nn.Module):
         if self.test_mode:
             return up
         return outs
+
+
+def two_stage_forward(model: CREStereoBase, frame1: torch.Tensor, frame2: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
+    """The "2-stage cascaded" inference of BASELINE.json config 5 (the reference model has the `flow_init` hook,
+    cre_stereo/model.py:205-212, but no caller): run the 3-scale cascade on the half-resolution pair, then the
+    full-resolution pair with `flow_init` = the half-resolution result (one stage of `iters` iterations at 1/8)."""
+    # half resolution, rounded up to a multiple of 32 (the cascade needs H/32 == (H/8)//4: model.py:172-174)
+    h, w = -(-(frame1.shape[2] // 2) // 32) * 32, -(-(frame1.shape[3] // 2) // 32) * 32
+    small = [F.interpolate(f, size=(h, w), mode="bilinear", align_corners=True) for f in (frame1, frame2)]
+    coarse = model(small[0], small[1])
+    init = coarse if torch.is_tensor(coarse) else coarse[-1]["up_disp"]
+    return model(frame1, frame2, flow_init=init)

@@ -247,6 +247,16 @@ def cre_stereo_forward(sd: SD, frame1: torch.Tensor, frame2: torch.Tensor, iters
     return outs
 
 
+def cre_two_stage_forward(sd: SD, frame1: torch.Tensor, frame2: torch.Tensor, iters: int) -> List[torch.Tensor]:
+    """BASELINE.json config 5 harness: cascade on the half-resolution pair, then the full-resolution pair
+    with flow_init = that result (the `flow_init` entry of cre_stereo/model.py:205-212, pinned by make_golden_cre.py)."""
+    # half resolution, rounded up to a multiple of 32 (the cascade needs H/32 == (H/8)//4: model.py:172-174)
+    h, w = -(-(frame1.shape[2] // 2) // 32) * 32, -(-(frame1.shape[3] // 2) // 32) * 32
+    s1, s2 = (F.interpolate(f, size=(h, w), mode="bilinear", align_corners=True) for f in (frame1, frame2))
+    coarse = cre_stereo_forward(sd, s1, s2, iters)
+    return cre_stereo_forward(sd, frame1, frame2, iters, flow_init=coarse[-1])
+
+
 # ------------------------------------------------------------------------ state-dict spec
 def cre_stereo_spec(fnet_dim: int = 256, hidden: int = 128):
     """(key, shape) list of CREStereoBase.state_dict() (cre_stereo/model.py:70-101) in registration order."""

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nndepth_amd import weightgen
-from nndepth_amd.cre_stereo import CREStereoBase
+from nndepth_amd.cre_stereo import CREStereoBase, two_stage_forward
 
 H, W, iters, reps = (int(a) for a in (sys.argv[1:5] + ["1080", "1920", "20", "3"][len(sys.argv) - 1:]))
 dev = "cuda:0"
@@ -22,3 +22,12 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 print(f"CREStereo {H}x{W} iters={iters}: {dt * 1e3:.1f} ms / pair  ({1 / dt:.2f} pairs/s), outputs {len(out)}, |flow|max {out[-1]['up_disp'].abs().max().item():.1f}")
+for _ in range(2):
+    out = two_stage_forward(m, f1, f2)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    out = two_stage_forward(m, f1, f2)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+print(f"CREStereo 2-stage (config 5 harness) {H}x{W} iters={iters}: {dt * 1e3:.1f} ms / pair  ({1 / dt:.2f} pairs/s)")

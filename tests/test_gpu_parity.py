@@ -619,3 +619,19 @@ def test_igev_forward_golden(gold):
     m.fused_loop = False
     seam = m(f1.to(DEV), f2.to(DEV))
     assert max((a["up_disp"] - b["up_disp"]).abs().max().item() for a, b in zip(outs, seam)) <= 5e-5
+
+
+def test_cre_two_stage_vs_oracle(cre_sd, CR):
+    """Config-5 harness: half-resolution cascade, then the full-resolution pass seeded with its result."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cre_stereo import CREStereoBase, two_stage_forward
+    fr1, fr2 = weightgen.synthetic_frames(8, 1, 256, 384)
+    m = CREStereoBase(iters=4)
+    m.load_state_dict(cre_sd, strict=True)
+    m = m.to(DEV).eval()
+    outs = two_stage_forward(m, fr1.to(DEV), fr2.to(DEV))
+    exp = CR.cre_two_stage_forward(cre_sd, fr1, fr2, 4)
+    assert len(outs) == len(exp) == 4
+    errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
+    print("\ncre two-stage max-abs:", " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) <= 1e-4
