@@ -443,6 +443,7 @@ struct TileCfg {
 static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, TileCfg* out) {
     int force_p = -1, force_ks = -1, force_wco = -1;
     if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &force_p, &force_ks, &force_wco);
+    if (const char* e = getenv("NND_CONV_P")) force_p = atoi(e);
     double best = 1e30;
     bool found = false;
     for (int ks : {1, 2})  // ks = 4 measured slower on every layer (scripts/sweep_conv.py)
@@ -454,7 +455,7 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
         if (wco > 1 && cdiv(L.ncb, wco) * wco >= L.ncb + wco) continue;  // a whole workgroup of idle waves
         const int nthreads = 64 * wco * ks;
         {
-            for (int P : {1, 2}) {
+            for (int P : {1}) {  // P = 2 (two sub-tiles per wave) measured slower on every config: 256 VGPRs + scratch
                 if (force_p > 0 && P != force_p) continue;
                 if (P == 2 && wco * ks > 8) continue;
                 const int SC = NND_SC, SR = 32 / NND_SC;
@@ -513,12 +514,8 @@ static int launch_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipS
 
 template <int KH, int KW, int CI_T>
 static int launch_shape(const ConvArgs& a, const TileCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
-    if (cfg.P == 1) {
-        if (cfg.ne <= 8) return launch_one<KH, KW, CI_T, 1, 8>(a, grid, block, cfg.lds, stream);
-        return launch_one<KH, KW, CI_T, 1, 16>(a, grid, block, cfg.lds, stream);
-    }
-    if (cfg.ne <= 8) return launch_one<KH, KW, CI_T, 2, 8>(a, grid, block, cfg.lds, stream);
-    return launch_one<KH, KW, CI_T, 2, 16>(a, grid, block, cfg.lds, stream);
+    if (cfg.ne <= 8) return launch_one<KH, KW, CI_T, 1, 8>(a, grid, block, cfg.lds, stream);
+    return launch_one<KH, KW, CI_T, 1, 16>(a, grid, block, cfg.lds, stream);
 }
 
 int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W,
