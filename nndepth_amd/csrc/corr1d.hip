@@ -253,52 +253,80 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
     return NND_OK;
 }
 
-// Fused lookup + encoder.convc1 (1x1, cor_planes -> 256, ReLU) for the refinement loop: one workgroup = one 4x8 pixel
-// tile x all 256 output channels (8 waves).  The cor_planes sampled values of the tile are computed straight into the
-// LDS B-operand (same arithmetic, same op order as corr1d_lookup_kernel), then every wave runs its cor_planes/2 MFMAs
-// against the packed convc1 weights (conv_mfma fragment order, CI_T = 32) and stores relu(acc + bias) as one 128-B line
-// per (channel, half-wave) of the tile-major c1 buffer.  Saves a launch and the (B,cor_planes,H,W) round trip; the
-// accumulation order is the one of conv_mfma with ks = 1, so the result is bit-identical to lookup -> convc1.
-__global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
-                                                            const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                            float* __restrict__ out, long obs, LookupArgs a, int tiles_x) {
-    __shared__ float xs[64 * 32];  // [channel][pixel of the tile]; channels >= cor_planes stay zero
+// Fused lookup + encoder.convc1 (1x1, cor_planes -> 256, ReLU) for the refinement loops: one workgroup = one 4x8 pixel
+// tile x all 256 output channels (8 waves).  The sampled correlation features are produced 32 channels at a time
+// straight into the LDS B-operand (same arithmetic and op order as corr1d_lookup_kernel / igev_lookup_kernel; the two
+// gathers of chunk c+1 are in flight while the MFMAs of chunk c issue), and every wave multiplies them with the packed
+// convc1 weights (conv_mfma fragment order, CI_T = 32).  Saves a launch and the (B,cor_planes,H,W) round trip — 75 MB
+// per iteration for IGEV's 576 planes.  The accumulation order is conv_mfma's with ks = 1.
+// IGEV = true: two pyramids, channel = lvl*(2*G*T) + v*(G*T) + g*T + k (igev_stereo/cost_volume.py:54-79).
+template <bool IGEV>
+__global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restrict__ pyr, const float* __restrict__ geo,
+                                                            const float* __restrict__ coords, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias, float* __restrict__ out, long obs,
+                                                            LookupArgs a, int G, int tiles_x, int cb_stride) {
+    __shared__ float xs[2][32 * 32];  // [buffer][channel of the chunk][pixel of the tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
     const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
-    const int ntap = 2 * a.radius + 1, nch = a.num_levels * ntap;
+    const int ntap = 2 * a.radius + 1;
+    const int nch = a.num_levels * ntap * (IGEV ? 2 * G : 1), nchunks = (nch + 31) / 32;
     const long HW = (long)a.H * a.W;
-    for (int e = tid; e < 64 * 32; e += 512) {
-        const int ch = e >> 5, px = e & 31;
-        const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
-        float v = 0.f;
-        if (ch < nch && y < a.H && x < a.W) {
-            const int lvl = ch / ntap, k = ch - lvl * ntap;
-            const int w2 = a.L.width[lvl];
-            const long pix = (long)y * a.W + x;
-            const float* row = pyr + a.L.off[lvl] + ((long)b * HW + pix) * w2;
-            float xx = (float)(k - a.radius) + coords[(long)b * a.lay.plane + pix_off(a.lay, y, x)] / (float)(1 << lvl);
-            const float wm1 = (float)(w2 - 1);
-            xx = xx / wm1;
-            xx = fminf(fmaxf(xx, 0.f), 1.f);
-            xx = xx * wm1;
-            const float f0 = floorf(xx), f1 = ceilf(xx);
-            const float v0 = row[(int)f0], v1 = row[(int)f1];
-            const float coef = f1 - xx;
-            v = coef * v0 + (1.0f - coef) * v1;
+    // staging role: pixel px of the tile, channels cs and cs + 16 of every chunk
+    const int px = tid & 31, cs = tid >> 5;
+    const int py = ty0 + (px >> 3), pxx = tx0 + (px & 7);
+    const bool pin = py < a.H && pxx < a.W;
+    const long pix = pin ? (long)py * a.W + pxx : 0;
+    const float cval = pin ? coords[(long)b * a.lay.plane + pix_off(a.lay, py, pxx)] : 0.f;
+    float v0[2], v1[2], cf[2];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = chunk * 32 + cs + 16 * j;
+            const bool ok = pin && ch < nch;
+            const int chc = ok ? ch : 0;
+            int k, lvl;
+            const float* base;
+            if (IGEV) {
+                k = chc % ntap;
+                const int g = (chc / ntap) % G, v = (chc / (ntap * G)) % 2;
+                lvl = chc / (ntap * G * 2);
+                base = (v ? geo : pyr) + a.L.off[lvl] + (((long)b * G + g) * HW + pix) * a.L.width[lvl];
+            } else {
+                lvl = chc / ntap;
+                k = chc - lvl * ntap;
+                base = pyr + a.L.off[lvl] + ((long)b * HW + pix) * a.L.width[lvl];
+            }
+            float x = cval / (float)(1 << lvl) + (float)(k - a.radius);
+            const float wm1 = (float)(a.L.width[lvl] - 1);
+            x = x / wm1;
+            x = fminf(fmaxf(x, 0.f), 1.f);
+            x = x * wm1;
+            const float f0 = floorf(x), f1 = ceilf(x);
+            v0[j] = base[(int)f0];
+            v1[j] = base[(int)f1];
+            cf[j] = ok ? f1 - x : 2.0f;  // 2.0 marks "no such channel / pixel": the store below writes 0
         }
-        xs[e] = v;
-    }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            xs[buf][(cs + 16 * j) * 32 + px] = cf[j] == 2.0f ? 0.f : cf[j] * v0[j] + (1.0f - cf[j]) * v1[j];
+    };
+    fetch(0);
+    put(0);
     __syncthreads();
     const int cb = wave;  // 8 waves = 256 output channels
-    const int nchunks = (nch + 31) / 32;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float4* wb = reinterpret_cast<const float4*>(wpk) + (size_t)cb * nchunks * (4 * 64);
+    // cb_stride: float4s per output-channel block of the packed layer (its K is padded to whole CI_T chunks)
+    const float4* wb = reinterpret_cast<const float4*>(wpk) + (size_t)cb * cb_stride;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) fetch(chunk + 1);
         const int npair = min(16, (nch - chunk * 32 + 1) / 2);  // k-pairs that hold real channels
-        const float* xb = xs + (chunk * 32 + h2) * 32 + l31;
+        const float* xb = xs[chunk & 1] + h2 * 32 + l31;
         for (int q = 0; q * 4 < npair; ++q) {
             const float4 av = wb[(size_t)chunk * (4 * 64) + q * 64 + lane];
             const float as[4] = {av.x, av.y, av.z, av.w};
@@ -306,6 +334,8 @@ __global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restr
             for (int j = 0; j < 4; ++j)
                 if (q * 4 + j < npair) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], xb[(q * 4 + j) * 64], acc, 0, 0, 0);
         }
+        if (more) put((chunk + 1) & 1);
+        __syncthreads();
     }
     const int y = ty0 + (l31 >> 3), x = tx0 + (l31 & 7);
     if (y >= a.H || x >= a.W) return;
@@ -317,19 +347,28 @@ __global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restr
     }
 }
 
-// coords (tile-major) -> c1 = relu(convc1(lookup(coords))) (tile-major, 256 channels); wpk / bias: the packed convc1 layer
-int lookup_convc1_launch(const float* pyr, const float* coords, const float* wpk, const float* bias, float* c1, int64_t c1_bs,
-                         int B, int H, int W, int num_levels, int radius, hipStream_t stream) {
-    NND_REQUIRE(num_levels >= 1 && num_levels < MAX_LEVELS && num_levels * (2 * radius + 1) <= 64,
-                "lookup_convc1: %d levels x %d taps not supported", num_levels, 2 * radius + 1);
+// coords (tile-major) -> c1 = relu(convc1(lookup(coords))) (tile-major, 256 channels); wpk / bias: the packed convc1 layer.
+// geo == nullptr: RAFT-Stereo pyramid; otherwise the IGEV feature + geometry pyramids with G groups.
+int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
+                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream) {
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 &&
+                    L.Cin == num_levels * (2 * radius + 1) * (geo ? 2 * G : 1),
+                "lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
+    const float* wpk = blob + L.w_off;
+    const float* bias = blob + L.b_off;
+    const int cb_stride = L.nchunks * (L.CI_T / 8) * 64;
+    NND_REQUIRE(num_levels >= 1 && num_levels < MAX_LEVELS, "lookup_convc1: num_levels %d out of range", num_levels);
     LookupArgs a;
-    make_layout(B, H, W, num_levels + 1, &a.L, nullptr);
+    make_layout(geo ? B * G : B, H, W, num_levels + 1, &a.L, nullptr);
     a.B = B; a.H = H; a.W = W; a.num_levels = num_levels; a.radius = radius;
     a.lay = make_lay(H, W, true);
     NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
     const int tiles_x = cdiv(W, 8);
-    hipLaunchKernelGGL(lookup_convc1_kernel, dim3(tiles_x * cdiv(H, 4), 1, B), dim3(512), 0, stream, pyr, coords, wpk, bias, c1,
-                       (long)c1_bs, a, tiles_x);
+    dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(512);
+    if (geo)
+        hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, G, tiles_x, cb_stride);
+    else
+        hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, 1, tiles_x, cb_stride);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

@@ -700,7 +700,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_up = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;  // read per call: the parity tests toggle these
     const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
-    const bool fused_lk = !cre && !igev && !no_fuse_lk && p.d.cor_planes <= 64;
+    const bool fused_lk = !cre && !no_fuse_lk;
     NND_HIP_CHECK(hipEventRecord(st->adv, s));
     for (int it = 0; it < iters; ++it) {
         NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
@@ -708,8 +708,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
         NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
         if (fused_lk) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
-            NND_TRY(lookup_convc1_launch(pyramid, w.coords, packed + p.L[C_C1].w_off, packed + p.L[C_C1].b_off, w.c1, 256 * n, B,
-                                         H, W, num_levels, radius, s));
+            NND_TRY(lookup_convc1_launch(pyramid, geo_pyramid, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W,
+                                         num_levels, radius, s));
         } else {
             NND_TRY(lookup(s, it));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
