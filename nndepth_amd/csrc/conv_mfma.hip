@@ -483,6 +483,9 @@ static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, T
                 double unit = (double)cdiv(L.nchunks, ks) * P;
                 double per_simd = std::ceil(waves / 1024.0);
                 double t = (per_simd <= occ) ? per_simd * unit : std::ceil(waves / (1024.0 * occ)) * occ * unit;
+                // a workgroup spreads its wco*ks waves round-robin over the 4 SIMDs of its CU: 6 waves load them (2,2,1,1), and
+                // measured launches of such workgroups run like 8 waves each (flow_head.conv1+mask.0: 78 vs 64 us)
+                t *= std::ceil(wco * ks / 4.0) * 4.0 / (wco * ks);
                 if (waves <= 1024.0) t *= 1.10;             // one wave per SIMD cannot hide its own stalls
                 t *= 1.0 + 0.02 * (4 - wco);                 // fewer waves share one staged patch
                 t *= 1.0 - 0.02 * (P - 1);                   // larger P: fewer weight bytes per flop

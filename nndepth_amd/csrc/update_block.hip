@@ -26,11 +26,11 @@ namespace nnd {
 // C_*X: GRU convs of the fused loop — input = [h | motion+flow] only; the contribution of the context features
 // `inp` (constant over the iterations of a pair) is precomputed once per pair by the C_*C convs and enters as a
 // per-pixel bias map.  C_ZR1..C_Q2 are the full convs used by the single-call API (nnd_update_block_forward).
-enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1X, C_Q1X, C_ZR2X, C_Q2X, C_FH1, C_M0, C_M2, C_LOOP_COUNT,
+enum ConvId { C_C1 = 0, C_C2, C_F2, C_CV, C_ZR1X, C_Q1X, C_ZR2X, C_Q2X, C_FHM, C_M2, C_LOOP_COUNT,
               C_ZR1 = C_LOOP_COUNT, C_Q1, C_ZR2, C_Q2, C_ZR1C, C_Q1C, C_ZR2C, C_Q2C, C_COUNT };
 static const char* kConvNames[C_COUNT] = {"encoder.convc1", "encoder.convc2", "encoder.convf2", "encoder.conv",
                                           "gru.convz1+convr1[h,motion]", "gru.convq1[rh,motion]", "gru.convz2+convr2[h,motion]",
-                                          "gru.convq2[rh,motion]", "flow_head.conv1", "mask.0", "mask.2",
+                                          "gru.convq2[rh,motion]", "flow_head.conv1+mask.0", "mask.2",
                                           "gru.convz1+convr1", "gru.convq1", "gru.convz2+convr2", "gru.convq2",
                                           "gru.convz1+convr1[inp]", "gru.convq1[inp]", "gru.convz2+convr2[inp]", "gru.convq2[inp]"};
 
@@ -88,8 +88,7 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
             p->L[base + 2] = p->L[base];
             p->L[base + 3] = p->L[base + 1];
         }
-    p->L[C_FH1] = mk(3, 3, hid, hid, &off);
-    p->L[C_M0] = mk(3, 3, hid, 2 * hid, &off);
+    p->L[C_FHM] = mk(3, 3, hid, 3 * hid, &off);  // flow_head.conv1 (hid) and mask.0 (2*hid): same input h, both ReLU -> one conv
     p->fc2_w = off; off += (int64_t)fc * hid * 9;
     p->fc2_b = off; off += 4;  // keep 16-B alignment of what follows
     p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off);
@@ -346,11 +345,7 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             io.src0 = act(w.hx + hid * n, hxC * n, ctx);
             io.out0 = act(w.ctxb + (id == C_Q1C ? 2 * hid : 5 * hid) * n, 6 * hid * n, hid);
             break;
-        case C_FH1: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, hid); break;
-        case C_M0:
-            io.src0 = act(w.hx, hxC * n, hid);
-            io.out0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
-            break;
+        case C_FHM: io.src0 = act(w.hx, hxC * n, hid); io.out0 = act(w.fm, 3 * hid * n, 3 * hid); break;
         case C_M2:
             io.src0 = act(w.fm + hid * n, 3 * hid * n, 2 * hid);
             io.out0 = act(mask_dst, p.d.mask_channels * n, p.d.mask_channels);
@@ -473,12 +468,9 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
         NND_TRY(run_conv(p, blob, w, C_ZR2, corr, nullptr, nullptr, B, H, W, s));
         NND_TRY(run_conv(p, blob, w, C_Q2, corr, nullptr, nullptr, B, H, W, s));
     }
-    NND_TRY(run_conv(p, blob, w, C_FH1, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_conv(p, blob, w, C_FHM, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_fc2(p, blob, w, delta_dst, 0, false, B, H, W, s));
-    if (mask_dst) {
-        NND_TRY(run_conv(p, blob, w, C_M0, corr, nullptr, nullptr, B, H, W, s));
-        NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
-    }
+    if (mask_dst) NND_TRY(run_conv(p, blob, w, C_M2, corr, mask_dst, nullptr, B, H, W, s));
     return NND_OK;
 }
 
@@ -572,8 +564,7 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
         gru(1, 16, 18, 20);
         k = 22;
     }
-    one(C_FH1, k);
-    one(C_M0, k + 4);
+    two(C_FHM, k, k + 4, hid, 2 * hid);
     memcpy(out + p.fc2_w, t[k + 2], sizeof(float) * fc * hid * 9);
     memcpy(out + p.fc2_b, t[k + 3], sizeof(float) * fc);
     one(C_M2, k + 6);
@@ -687,8 +678,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     for (int id : {(int)C_ZR1C, (int)C_Q1C, (int)C_ZR2C, (int)C_Q2C})
         if (p.sep || id < C_ZR2C) NND_TRY(run_conv(p, packed, w, id, c, nullptr, nullptr, B, H, W, s));
     // Per-iteration schedule over two streams (M = caller's stream carries the recurrence):
-    //   M: lookup (+convc1), convc2, [f2] conv, zr1, q1, zr2, q2, flow_head.conv1, flow_head.conv2+advance ->(adv),
-    //      mask.0, mask.2 + convex upsample (fused)
+    //   M: lookup (+convc1), convc2, [f2] conv, zr1, q1, zr2, q2, flow_head.conv1+mask.0, flow_head.conv2+advance ->(adv),
+    //      mask.2 + convex upsample (fused)
     //   A: (adv) convf1, convf2 ->(f2)                              flow branch of the motion encoder
     // Measured on MI355X at 544x960 (ms per pair): M+A 17.6 | M+A+B (mask branch on a third stream, which needs a
     // double-buffered copy of h and 3 more event operations on M per iteration) 18.0 | everything on M 17.7 | M only,
@@ -723,10 +714,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(run_conv(p, packed, w, C_ZR2X, c, nullptr, nullptr, B, H, W, s));
             NND_TRY(run_conv(p, packed, w, C_Q2X, c, nullptr, nullptr, B, H, W, s));
         }
-        NND_TRY(run_conv(p, packed, w, C_FH1, c, nullptr, nullptr, B, H, W, s));
+        NND_TRY(run_conv(p, packed, w, C_FHM, c, nullptr, nullptr, B, H, W, s));  // flow_head.conv1 and mask.0 in one launch
         NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
         NND_HIP_CHECK(hipEventRecord(st->adv, s));  // the flow is final: stream A may start the next flow branch
-        NND_TRY(run_conv(p, packed, w, C_M0, c, nullptr, nullptr, B, H, W, s));
         float* up_it = up_out + (int64_t)it * up_iter_stride;
         if (fused_up) {  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
             NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow, up_it, B, H, W, rate, s,
