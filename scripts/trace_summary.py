@@ -25,3 +25,13 @@ main = [r for r in seq if r["Queue_Id"] == mq]
 gaps = sum(max(0, int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) for a, b in zip(main[:-1], main[1:])) / 1e3
 span = (int(main[-1]["End_Timestamp"]) - int(main[0]["Start_Timestamp"])) / 1e3
 print(f"main stream: span {span/1e3:.2f} ms, kernels {tot_main/1e3:.2f} ms, gaps {gaps/1e3:.2f} ms")
+
+# stand-alone launches of bench.py's roofline leg (nnd_profile_conv: 1 warm + 20 timed launches per layer, after the steps)
+tail = [r for r in rows[last + 1:] if "conv_mfma" in r["Kernel_Name"]]
+g2 = collections.OrderedDict()
+for r in tail:
+    k = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Workgroup_Size_X"])
+    g2.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("stand-alone conv launches after the timed region (bench.py roofline leg):")
+for k, v in g2.items():
+    print(f"  {k[0]:32s} grid {k[1]:>7s} wg {k[2]:>4s} n {len(v):4d} avg {sum(v)/len(v):7.1f} us")
