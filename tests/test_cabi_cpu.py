@@ -172,3 +172,22 @@ def test_encoder_pack_host(raft_sd):
         ops.EncoderEngine(256, "instance", 0)
     with pytest.raises(NndError):
         ops.EncoderEngine(256, "batch", 192).load(enc_sd, None, device="cpu")
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call: the CRE / encoder / conv entry points must return a negative
+    status (never crash) on a CPU-only host."""
+    from nndepth_amd._lib import lib, ConvDesc, EncoderDesc, UpdateBlockDesc
+    assert lib.nnd_bilinear_sample(None, None, None, 1, 4, 8, 8, 4, 4, None) < 0
+    assert lib.nnd_agcl_corr_iter(None, None, None, None, None, 1, 32, 8, 8, 0, None) < 0
+    assert lib.nnd_agcl_corr_offset(None, None, None, None, None, 1, 32, 8, 8, 0, None) < 0
+    assert lib.nnd_softargmin_disparity(None, None, 1, 8, 4, 4, None) < 0
+    d = ConvDesc(16, 16, 3, 3, 3)
+    assert lib.nnd_conv_packed_floats(C.byref(d)) < 0 and b"stride" in lib.nnd_last_error()
+    assert lib.nnd_conv_forward(C.byref(ConvDesc(16, 16, 3, 3, 1)), None, None, None, None, 1, 8, 8, 0, 0, None) < 0
+    e = EncoderDesc(256, 2, 0)  # instance norm is not built
+    assert lib.nnd_encoder_packed_floats(C.byref(e)) < 0
+    assert lib.nnd_encoder_forward(C.byref(EncoderDesc(256, 1, 0)), None, None, None, None, 0, None, 2, 64, 64, None) < 0
+    u = UpdateBlockDesc(128, 128, 36, 2, 576, 0)
+    assert lib.nnd_cre_stereo_refine(C.byref(u), None, None, None, 256, None, None, None, None, None, None, 0, None, None, None,
+                                     1, 8, 8, 8, 2, None) < 0
