@@ -194,6 +194,25 @@ int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* tensors_h
 int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed_dev, const float* frames, float* fmap,
                         float* cnet_out, int n_cnet, float* workspace, int N, int H, int W, void* stream);
 
+/* ------------------------------------------------------------- pre- / post-processing on the device
+ * nnd_resize_normalize : preprocess_frame  nndepth/models/raft_stereo/scripts/inference.py:55-60
+ *     dst (B,C,H,W) = (bilinear_resize(src) - sub) / div, bilinear as F.interpolate(mode="bilinear") (align_corners=False);
+ *     src is float (B,C,h,w), or — src_is_u8_hwc != 0 — the decoded image itself, uint8 (B,h,w,C).
+ * nnd_replicate_pad    : Padder.pad / unpad  nndepth/data/dataloaders/utils.py:5-21
+ *     dst (B,C,H+top+bottom,W+left+right) = F.pad(src, (left,right,top,bottom), mode="replicate"); negative values crop.
+ * nnd_epe_metrics      : EvalCriterion.__call__  nndepth/models/raft_stereo/scripts/evaluate.py:48-83 (equal-size inputs)
+ *     epe = sqrt(sum_c (pred-gt)^2); valid = sqrt(sum_c gt^2) < max_flow (and valid_mask != 0 if given, (B,H,W) bytes);
+ *     out[0] = mean epe over valid, out[1] = number of valid pixels, out[2+k] = fraction of valid pixels with
+ *     epe > thresholds[k].  `thresholds` is a HOST array (<= 4 entries); `workspace` = nnd_epe_metrics_workspace_bytes()
+ *     device bytes; `out` = 2 + num_thresholds device floats.  Deterministic (two-stage double-precision reduction).   */
+int nnd_resize_normalize(const void* src, int src_is_u8_hwc, float* dst, int B, int C, int h, int w, int H, int W,
+                         float sub, float div, void* stream);
+int nnd_replicate_pad(const float* src, float* dst, int B, int C, int H, int W, int left, int right, int top, int bottom,
+                      void* stream);
+int64_t nnd_epe_metrics_workspace_bytes(void);
+int nnd_epe_metrics(const float* disp_gt, const float* disp_pred, const unsigned char* valid_mask, int B, int C, int H, int W,
+                    float max_flow, const float* thresholds_host, int num_thresholds, void* workspace, float* out, void* stream);
+
 /* Fused tail of the mask head + convex upsample (the (B, 9*rate^2, H, W) mask is never written):
  *   out = convex_upsample(flow, 0.25 * conv1x1(x; W, b))      x (B,Cin,H,W), flow (B,1,H,W), out (B,1,rate*H,rate*W)
  * Replaces update_block.py:97-101,111 (mask.2, x0.25) + raft_stereo/model.py:93-105.  `packed_dev` is the blob of

@@ -68,6 +68,10 @@ SIGNATURES = {
     "nnd_encoder_workspace_floats": (C.c_int64, [C.POINTER(EncoderDesc), _I, _I, _I]),
     "nnd_encoder_pack": (_I, [C.POINTER(EncoderDesc), C.POINTER(_P), C.c_float, _P]),
     "nnd_encoder_forward": (_I, [C.POINTER(EncoderDesc), _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "nnd_resize_normalize": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
+    "nnd_replicate_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_epe_metrics_workspace_bytes": (C.c_int64, []),
+    "nnd_epe_metrics": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_float, C.POINTER(C.c_float), _I, _P, _P, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
                               C.POINTER(C.c_double)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),

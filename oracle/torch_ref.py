@@ -232,6 +232,51 @@ def igev_init_disparity(logits: torch.Tensor) -> torch.Tensor:
     return -torch.sum(disp * dist, dim=1, keepdim=True)
 
 
+# --------------------------------------------------------------------- pre- / post-processing
+def preprocess_frame(frame: torch.Tensor, HW) -> torch.Tensor:
+    """nndepth/models/raft_stereo/scripts/inference.py:55-60: (3,h,w) float in 0..255 -> (1,3,H,W) in [-1,1]."""
+    frame = F.interpolate(frame.unsqueeze(0), tuple(HW), mode="bilinear")
+    return (frame - 127.5) / 127.5
+
+
+def padder_pads(HW, divis_by: int = 8):
+    """nndepth/data/dataloaders/utils.py:7-11 -> [left, right, top, bottom]."""
+    ht, wd = HW
+    pad_ht = (((ht // divis_by) + 1) * divis_by - ht) % divis_by
+    pad_wd = (((wd // divis_by) + 1) * divis_by - wd) % divis_by
+    return [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+
+
+def padder_pad(x: torch.Tensor, pads) -> torch.Tensor:
+    """utils.py:13-15."""
+    return F.pad(x, pads, mode="replicate")
+
+
+def padder_unpad(x: torch.Tensor, pads) -> torch.Tensor:
+    """utils.py:17-21."""
+    ht, wd = x.shape[-2:]
+    return x[..., pads[2]:ht - pads[3], pads[0]:wd - pads[1]]
+
+
+def eval_criterion(disp_gt: torch.Tensor, disp_pred: torch.Tensor, valid_mask=None, d_threshold=None, max_flow: float = 1000):
+    """nndepth/models/raft_stereo/scripts/evaluate.py:48-83."""
+    if disp_pred.shape[-2:] != disp_gt.shape[-2:]:
+        scale = disp_gt.shape[-1] // disp_pred.shape[-1]
+        gt = -F.max_pool2d(-disp_gt, kernel_size=scale) / scale
+        gt = F.interpolate(gt, size=disp_pred.shape[-2:])
+    else:
+        gt = disp_gt
+    e = torch.sum((disp_pred - gt) ** 2, dim=1).sqrt()
+    valid = torch.sum(gt ** 2, dim=1, keepdim=True).sqrt() < max_flow
+    if valid_mask is not None:
+        valid = valid & valid_mask
+    e = e.view(-1)[valid.view(-1)]
+    out = {"epe": e.mean().item()}
+    for k, thr in (d_threshold or {}).items():
+        out[k] = (e > thr).float().mean().item()
+    return out
+
+
 def epe(disp_gt: torch.Tensor, disp_pred: torch.Tensor, max_flow: float = 1000.0) -> float:
     """nndepth/models/raft_stereo/scripts/evaluate.py:62-83 for equal-size inputs."""
     e = torch.sum((disp_pred - disp_gt) ** 2, dim=1).sqrt()

@@ -635,3 +635,56 @@ def test_cre_two_stage_vs_oracle(cre_sd, CR):
     errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
     print("\ncre two-stage max-abs:", " ".join(f"{e:.1e}" for e in errs))
     assert max(errs) <= 1e-4
+
+
+# ------------------------------------------------------------ pre- / post-processing on the device
+def test_preprocess_frame_golden(gold):
+    """Bilinear resize + normalisation, from the float CHW frame and straight from the decoded uint8 HWC image, against
+    the reference's preprocess_frame (ATen's index / weight arithmetic is followed step by step: <= 2 ulp of 255)."""
+    from nndepth_amd.prepost import preprocess_frame
+    g = gold("prepost.npz")
+    img = t(g["pre_img_u8"])
+    fr = img.permute(2, 0, 1).float().contiguous()
+    for name, HW in (("down", (68, 120)), ("odd", (77, 131)), ("up", (150, 333))):
+        a = preprocess_frame(fr.to(DEV), HW).cpu().numpy()
+        b = preprocess_frame(img.to(DEV), HW).cpu().numpy()
+        assert np.array_equal(a, b)
+        err = np.abs(a - g[f"pre_{name}"]).max()
+        print(f"preprocess {name}: max-abs {err:.2e}")
+        assert err <= 5e-7, name
+
+
+def test_padder_golden(gold):
+    from nndepth_amd.prepost import Padder
+    g = gold("prepost.npz")
+    assert Padder((375, 1242), divis_by=32)._pad == [3, 3, 0, 9]
+    for name, (H, W, div) in (("odd8", (37, 53, 8)), ("exact", (64, 96, 8))):
+        x = t(g[f"pad_{name}_x"]).to(DEV)
+        pd = Padder((H, W), divis_by=div)
+        y = pd.pad(x)[0]
+        assert np.array_equal(y.cpu().numpy(), g[f"pad_{name}_y"])
+        assert torch.equal(pd.unpad(y), x)
+
+
+def test_eval_criterion_golden(gold):
+    from nndepth_amd.prepost import EvalCriterion
+    g = gold("prepost.npz")
+    for name in ("plain", "masked"):
+        mask = t(g[f"ev_{name}_mask"]).to(DEV) if f"ev_{name}_mask" in g else None
+        out = EvalCriterion({"kitti-d1": 3.0, "d5": 5.0}, max_flow=1000)(t(g[f"ev_{name}_gt"]).to(DEV), t(g[f"ev_{name}_pred"]).to(DEV), mask)
+        assert [out["epe"], out["kitti-d1"], out["d5"]] == pytest.approx(list(g[f"ev_{name}_out"]), rel=2e-6, abs=1e-7)
+
+
+def test_epe_parity_on_device(gold, raft_sd, tartanair_frames):
+    """The SURVEY §8d EPE-parity metric computed entirely on the device: EvalCriterion on the 544x960 TartanAir output."""
+    from nndepth_amd.prepost import EvalCriterion
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    g = gold("forward_tartanair.npz")
+    m = BaseRAFTStereo(iters=32, context_dim=64)
+    m.load_state_dict(raft_sd)
+    m = m.to(DEV).eval()
+    up = m(*[f.to(DEV) for f in tartanair_frames])[-1]["up_disp"]
+    gt = t(g["gt_disp"].astype(np.float32)).to(DEV)
+    ours = EvalCriterion({"d3": 3.0})(gt, up)
+    ref = EvalCriterion({"d3": 3.0})(gt, t(g["up_disp_it32"]).to(DEV))
+    assert abs(ours["epe"] - ref["epe"]) <= 1e-4 and abs(ours["d3"] - ref["d3"]) <= 1e-6

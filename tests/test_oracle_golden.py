@@ -105,3 +105,21 @@ def test_igev_model_keys_and_init_disparity(gold):
     m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=4, hidden_dim=64, context_dim=64)
     assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
     assert np.array_equal(R.igev_init_disparity(t(g["logits"])).numpy(), g["init"])
+
+
+def test_prepost_oracle(gold):
+    """§8f-3: preprocess_frame, Padder, EvalCriterion restatements against the imported reference's outputs."""
+    g = gold("prepost.npz")
+    fr = t(g["pre_img_u8"].transpose(2, 0, 1).copy()).float()
+    for name, HW in (("down", (68, 120)), ("odd", (77, 131)), ("up", (150, 333))):
+        assert np.array_equal(R.preprocess_frame(fr, HW).numpy(), g[f"pre_{name}"])
+    assert R.padder_pads((375, 1242), 32) == [3, 3, 0, 9] == list(g["pad_kitti32_pads"])  # SURVEY §8a, config K
+    for name, (H, W, div) in (("odd8", (37, 53, 8)), ("exact", (64, 96, 8))):
+        pads = R.padder_pads((H, W), div)
+        assert pads == list(g[f"pad_{name}_pads"])
+        y = R.padder_pad(t(g[f"pad_{name}_x"]), pads)
+        assert np.array_equal(y.numpy(), g[f"pad_{name}_y"]) and torch.equal(R.padder_unpad(y, pads), t(g[f"pad_{name}_x"]))
+    for name in ("plain", "masked"):
+        mask = t(g[f"ev_{name}_mask"]) if f"ev_{name}_mask" in g else None
+        out = R.eval_criterion(t(g[f"ev_{name}_gt"]), t(g[f"ev_{name}_pred"]), mask, {"kitti-d1": 3.0, "d5": 5.0}, 1000)
+        assert [out["epe"], out["kitti-d1"], out["d5"]] == pytest.approx(list(g[f"ev_{name}_out"]), abs=1e-7)
