@@ -178,7 +178,8 @@ int nnd_conv_forward(const nnd_conv_desc* desc, const float* packed_dev, const f
  * Replaces BasicEncoder.forward  nndepth/encoders/basic_encoder.py:71-93 (norm_fn "batch" in eval mode, or "none"),
  * ResidualBlock.forward nndepth/blocks/residual_block.py:53-60 and, optionally, the context projection
  * `cnet_proj` of nndepth/models/raft_stereo/model.py:53-55 applied to the first n_cnet maps (the left frames).
- * norm: 0 = none, 1 = BatchNorm2d (running statistics).  cnet_dim: output channels of cnet_proj, 0 = absent.
+ * norm: 0 = none, 1 = BatchNorm2d (running statistics, folded at pack time), 2 = InstanceNorm2d(affine=False) (CREStereo,
+ * cre_stereo/model.py:70-72; per-sample statistics computed on the device).  cnet_dim: channels of cnet_proj, 0 = absent.
  * nnd_encoder_pack (HOST): `tensors` = units of 6 pointers {weight, bias, norm weight, norm bias, running_mean,
  * running_var} (the last four NULL where there is no norm) in the order: conv1 | for each residual block layer1.0,
  * layer1.1, layer2.0, layer2.1, layer3.0, layer3.1: conv1, conv2, downsample.0 (its norm = norm3) | conv2 | cnet_proj.0.

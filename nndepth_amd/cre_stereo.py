@@ -4,8 +4,9 @@
 `forward(frame1, frame2, flow_init=None) -> List[{"up_disp": (N,2,H,W)}]` of
 nndepth/models/cre_stereo/model.py:17-288.  Inside `forward()`:
 
-    encoder (instance norm), avg-pools, offset convs, sine position encoding, LoFTR self/cross attention
-                              PyTorch-ROCm (adjacent rows, SURVEY §8f-1 / §8f-4)
+    encoder (instance norm)                              HIP  csrc/encoder.hip (nnd_encoder_forward, norm = instance)  model.py:139
+    avg-pools, offset convs, sine position encoding, LoFTR self/cross attention
+                              PyTorch-ROCm (adjacent rows, SURVEY §8f-4)
     AGCL (warp + window correlation, offset sampling)     HIP  csrc/agcl.hip          model.py:204-206,229,252,277
     update block (2-channel flow)                         HIP  csrc/update_block.hip  model.py:231,254,279
     convex upsample (2-channel)                           HIP  csrc/corr1d.hip        model.py:234,257,282
@@ -22,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .blocks import BasicUpdateBlock
 from .cost_volume import AGCL
 from .encoder import BasicEncoder
@@ -96,7 +98,7 @@ class CREStereoBase(nn.Module):
                  max_disp: int = 192, num_fnet_channels: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  search_num: int = 9, mixed_precision: bool = False, test_mode: bool = False, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, **kwargs):
+                 fused_loop: bool = True, hip_encoder: bool = True, **kwargs):
         super().__init__()
         if fnet_cls != "basic_encoder" or update_cls != "basic_update_block":
             raise ValueError("CREStereoBase: only basic_encoder / basic_update_block exist (as in the reference)")
@@ -108,6 +110,8 @@ class CREStereoBase(nn.Module):
         self.hidden_dim, self.context_dim, self.search_num = hidden_dim, context_dim, search_num
         self.tracing, self.include_preprocessing = tracing, include_preprocessing
         self.fused_loop = fused_loop
+        self.hip_encoder = hip_encoder
+        self._enc_engine, self._enc_version = None, None
         self.fnet = BasicEncoder(output_dim=num_fnet_channels, norm_fn="instance", dropout=0)
         self.fnet_ds = 8
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=4 * 9, flow_channel=2,
@@ -124,6 +128,22 @@ class CREStereoBase(nn.Module):
 
     def convex_upsample(self, flow, mask, rate=4):
         return convex_upsample(flow, mask, rate)
+
+    def forward_fnet(self, frame1: torch.Tensor, frame2: torch.Tensor):
+        """fnet([frame1, frame2]) (model.py:139); on the GPU at inference the instance-norm encoder runs in HIP
+        (csrc/encoder.hip, norm = instance: raw convs + per-sample statistics + one fused apply pass per block)."""
+        if self.hip_encoder and frame1.is_cuda and not self.training and self.fnet.dropout is None:
+            tensors = list(self.fnet.state_dict().values())
+            v = (tuple((t.data_ptr(), t._version) for t in tensors), str(frame1.device))
+            if v != self._enc_version:
+                if self._enc_engine is None:
+                    self._enc_engine = ops.EncoderEngine(self.fnet.conv2.out_channels, self.fnet.norm_fn, 0)
+                self._enc_engine.load(self.fnet.state_dict(), None, device=frame1.device)
+                self._enc_version = v
+            B = frame1.shape[0]
+            fmaps, _ = self._enc_engine.forward(torch.cat([frame1, frame2], 0).float())
+            return fmaps[:B], fmaps[B:]
+        return self.fnet([frame1, frame2])
 
     def _stage(self, corr_fn, net, inp, flow, offset, n_iters: int, iter_mode: bool, outs: List[Dict[str, torch.Tensor]]):
         if self.fused_loop and isinstance(corr_fn, AGCL) and n_iters > 0:
@@ -148,7 +168,7 @@ class CREStereoBase(nn.Module):
                 upsample: bool = True, test_mode: bool = False, **kwargs):
         frame1, frame2 = frame1.contiguous(), frame2.contiguous()
         hd, ds = self.hidden_dim, self.fnet_ds
-        fmap1, fmap2 = self.fnet([frame1, frame2])
+        fmap1, fmap2 = self.forward_fnet(frame1, frame2)
         fmap1, fmap2 = fmap1.float(), fmap2.float()
         net, inp = torch.split(fmap1, [hd, hd], dim=1)
         net, inp = torch.tanh(net), F.relu(inp)

@@ -13,6 +13,11 @@
 //   conv2 1x1 (128 -> output_dim)                    conv_mfma, writes the NCHW result
 //   cnet_proj 3x3 (output_dim -> ctx + hid) + ReLU   conv_mfma on the first half of the batch (the left frames)
 //
+// norm = 2 (InstanceNorm2d(affine=False), CREStereo's encoder, cre_stereo/model.py:70-72): the statistics depend on the
+// sample, so every conv writes its raw output (+ bias), `in_stats_kernel` reduces each (sample, channel) plane to
+// (1/sqrt(var + eps), -mean/sqrt(var + eps)) in double precision, and `in_apply_kernel` normalises in place with the ReLU
+// — for the block's last conv together with the normalised shortcut, the add and the final ReLU (one pass instead of four).
+//
 // Eval-mode BatchNorm is folded at pack time (host, double precision) into a per-channel scale and shift applied in the
 // conv epilogue: y = acc * (gamma / sqrt(var + eps)) + ((bias - mean) * gamma / sqrt(var + eps) + beta).
 // Intermediate activations live in the tile-major workspace layout (layout.h); the input frames and the outputs are NCHW.
@@ -97,7 +102,7 @@ static int run_conv_norm(const ConvLayer& L, const float* base, const float* x, 
 __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ out, long obs, int Hin, int Win, int H, int W,
-                                                   int tiles_x, Lay lay) {
+                                                   int tiles_x, Lay lay, int relu) {
     __shared__ float patch[3][21][72];
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
@@ -129,8 +134,94 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < 147; ++i) acc = fmaf(wc[i], v[i], acc);
         acc = fmaf(acc, scale[co], shift[co]);
-        if (ok) o[(long)co * lay.plane] = fmaxf(acc, 0.f);
+        if (ok) o[(long)co * lay.plane] = relu ? fmaxf(acc, 0.f) : acc;
     }
+}
+
+// ------------------------------------------------------------------------------------------ instance norm
+// stats[(n*C + c)*2 + {0,1}] = (alpha, beta) with alpha = 1/sqrt(var + eps), beta = -mean*alpha (biased variance, like
+// F.instance_norm).  Two deterministic stages with double-precision sums: IN_CHUNKS workgroups per (channel, sample)
+// plane of the tile-major tensor write partial (sum, sum of squares); one thread per plane combines them in order.
+constexpr int IN_CHUNKS = 32;
+__global__ void __launch_bounds__(256) in_partial_kernel(const float* __restrict__ x, long bs, int C, int H, int W, Lay lay,
+                                                         double* __restrict__ partial) {
+    __shared__ double sh[2][256];
+    const int k = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+    const float* p = x + (long)n * bs + (long)c * lay.plane;
+    double s = 0.0, q = 0.0;
+    const int HW = H * W;
+    for (int i = k * 256 + threadIdx.x; i < HW; i += IN_CHUNKS * 256) {
+        const int y = i / W, xx = i - y * W;
+        const double v = (double)p[pix_off(lay, y, xx)];
+        s += v;
+        q += v * v;
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int j = 128; j > 0; j >>= 1) {
+        if ((int)threadIdx.x < j) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + j];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = partial + (((long)n * C + c) * IN_CHUNKS + k) * 2;
+        o[0] = sh[0][0];
+        o[1] = sh[1][0];
+    }
+}
+
+__global__ void __launch_bounds__(256) in_final_kernel(const double* __restrict__ partial, int NC, int HW, float eps,
+                                                       float* __restrict__ stats) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // plane index n*C + c
+    if (i >= NC) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < IN_CHUNKS; ++k) {
+        s += partial[((long)i * IN_CHUNKS + k) * 2];
+        q += partial[((long)i * IN_CHUNKS + k) * 2 + 1];
+    }
+    const double mean = s / HW, var = fmax(q / HW - mean * mean, 0.0);
+    const double alpha = 1.0 / sqrt(var + (double)eps);
+    stats[(long)i * 2] = (float)alpha;
+    stats[(long)i * 2 + 1] = (float)(-mean * alpha);
+}
+
+// y = relu(x*alpha + beta) in place; with a shortcut: y = relu((sc*alpha_s + beta_s) + relu(x*alpha + beta)).
+// One thread per pixel of a (channel, sample) plane (tile-major incl. its padding: harmless, never read as data).
+__global__ void __launch_bounds__(256) in_apply_kernel(float* __restrict__ x, long bs, const float* __restrict__ stats,
+                                                       const float* __restrict__ sc, long sbs, const float* __restrict__ sstats,
+                                                       int C, long plane, int relu) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float a = stats[((long)n * C + c) * 2], b = stats[((long)n * C + c) * 2 + 1];
+    float* p = x + (long)n * bs + (long)c * plane + i;
+    float v = fmaf(*p, a, b);
+    if (relu) v = fmaxf(v, 0.f);
+    if (sc) {
+        const float as = sstats[((long)n * C + c) * 2], bsft = sstats[((long)n * C + c) * 2 + 1];
+        v = fmaxf(fmaf(sc[(long)n * sbs + (long)c * plane + i], as, bsft) + v, 0.f);
+    }
+    *p = v;
+}
+
+static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, float eps, float* stats, double* partial, hipStream_t s) {
+    hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, C, N), dim3(256), 0, s, x, (long)bs, C, H, W, make_lay(H, W, true), partial);
+    NND_LAUNCH_CHECK();
+    hipLaunchKernelGGL(in_final_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const double*)partial, N * C, H * W, eps, stats);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+static int in_apply(float* x, int64_t bs, const float* stats, const float* sc, int64_t sbs, const float* sstats, int N, int C, int H,
+                    int W, bool relu, hipStream_t s) {
+    const long plane = tiled_plane(H, W);
+    hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)cdiv64(plane, 256), C, N), dim3(256), 0, s, x, (long)bs, stats, sc, (long)sbs,
+                       sstats, C, plane, relu ? 1 : 0);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
 }
 
 // ------------------------------------------------------------------------------------------ encoder plan
@@ -151,8 +242,7 @@ struct EncPlan {
 static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
     NND_REQUIRE(d, "encoder: null descriptor");
     NND_REQUIRE(d->output_dim > 0 && d->cnet_dim >= 0, "encoder: bad output_dim / cnet_dim");
-    NND_REQUIRE(d->norm == 0 || d->norm == 1, "encoder: norm must be 0 (none) or 1 (batch, eval); instance / group norm "
-                "need per-sample statistics and are not built");
+    NND_REQUIRE(d->norm >= 0 && d->norm <= 2, "encoder: norm must be 0 (none), 1 (batch, eval) or 2 (instance); group norm is not built");
     p->d = *d;
     int64_t off = 0;
     p->stem_w = off; off += 64 * 147;
@@ -245,7 +335,8 @@ int64_t nnd_encoder_packed_floats(const nnd_encoder_desc* desc) {
 int64_t nnd_encoder_workspace_floats(const nnd_encoder_desc* desc, int N, int H, int W) {
     EncPlan p;
     if (make_enc_plan(desc, &p) != NND_OK || N <= 0 || H <= 0 || W <= 0) return NND_ERR_INVALID;
-    return 4 * enc_buf_floats(N, H, W);
+    // + instance-norm statistics (3 slots) and the partial sums of one reduction (doubles)
+    return 4 * enc_buf_floats(N, H, W) + (desc->norm == 2 ? (int64_t)3 * N * 256 + (int64_t)N * 128 * IN_CHUNKS * 2 * 2 : 0);
 }
 
 // tensors: units of 6 pointers (weight, bias, norm gamma, norm beta, running mean, running var; the last four NULL
@@ -310,11 +401,18 @@ int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const
     const int64_t bufsz = enc_buf_floats(N, H, W);
     float* buf[4] = {workspace, workspace + bufsz, workspace + 2 * bufsz, workspace + 3 * bufsz};
     int h = (H + 1) / 2, w = (W + 1) / 2;
+    const bool inorm = desc->norm == 2;
+    const float eps = 1e-5f;  // nn.InstanceNorm2d default, as constructed by the reference (basic_encoder.py:33-34)
+    float* st_a = workspace + 4 * bufsz;  // instance-norm statistics: 3 slots of N * 128 * 2 floats
+    float* st_b = st_a + (int64_t)N * 256;
+    float* st_c = st_b + (int64_t)N * 256;
+    double* part = reinterpret_cast<double*>(st_c + (int64_t)N * 256);  // 8-byte aligned: every offset above is a multiple of 64 floats
     {  // stem -> buf[0]
         const Lay lay = make_lay(h, w, true);
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 8);
         hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 2, N), dim3(256), 0, s, frames, packed + p.stem_w,
-                           packed + p.stem_scale, packed + p.stem_shift, buf[0], (long)(64 * lay.plane), H, W, h, w, tiles_x, lay);
+                           packed + p.stem_scale, packed + p.stem_shift, buf[0], (long)(64 * lay.plane), H, W, h, w, tiles_x, lay,
+                           inorm ? 0 : 1);
         NND_LAUNCH_CHECK();
     }
     int cur = 0;  // buffer holding the block input
@@ -322,6 +420,10 @@ int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const
     do {                              \
         if ((rc = (x)) != NND_OK) return rc; \
     } while (0)
+    if (inorm) {  // norm1 + ReLU of the stem
+        NND_TRY(in_stats(buf[0], 64 * tiled_plane(h, w), N, 64, h, w, eps, st_a, part, s));
+        NND_TRY(in_apply(buf[0], 64 * tiled_plane(h, w), st_a, nullptr, 0, nullptr, N, 64, h, w, true, s));
+    }
     for (int i = 0; i < ENC_BLOCKS; ++i) {
         const int st = p.strides[i], cin = p.inpl[i], dim = p.planes[i];
         const int ho = (h + st - 1) / st, wo = (w + st - 1) / st;
@@ -330,9 +432,20 @@ int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const
         float* y = buf[(cur + 1) & 3];
         float* sc = buf[(cur + 2) & 3];
         float* o = buf[(cur + 3) & 3];
-        NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 1, N, h, w, s));
-        NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s));
-        NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, sc, dim * pout, o, dim * pout, true, 3, N, ho, wo, s));
+        if (!inorm) {
+            NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 1, N, h, w, s));
+            NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s));
+            NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, sc, dim * pout, o, dim * pout, true, 3, N, ho, wo, s));
+        } else {  // raw convs + per-sample statistics; the shortcut is normalised inside the block's final apply pass
+            NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 0, N, h, w, s));
+            NND_TRY(in_stats(y, dim * pout, N, dim, ho, wo, eps, st_a, part, s));
+            NND_TRY(in_apply(y, dim * pout, st_a, nullptr, 0, nullptr, N, dim, ho, wo, true, s));
+            NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s));
+            NND_TRY(in_stats(sc, dim * pout, N, dim, ho, wo, eps, st_b, part, s));
+            NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, nullptr, 0, o, dim * pout, true, 0, N, ho, wo, s));
+            NND_TRY(in_stats(o, dim * pout, N, dim, ho, wo, eps, st_c, part, s));
+            NND_TRY(in_apply(o, dim * pout, st_c, sc, dim * pout, st_b, N, dim, ho, wo, true, s));
+        }
         cur = (cur + 3) & 3;
         h = ho; w = wo;
     }

@@ -431,10 +431,10 @@ class EncoderEngine:
     `cnet_sd` with `0.weight` / `0.bias` of the cnet_proj Sequential."""
 
     def __init__(self, output_dim: int, norm: str = "batch", cnet_dim: int = 0):
-        if norm not in ("batch", "none"):
-            raise NndError(f"EncoderEngine: norm_fn '{norm}' is not built in HIP (batch in eval mode, none)")
+        if norm not in ("batch", "none", "instance"):
+            raise NndError(f"EncoderEngine: norm_fn '{norm}' is not built in HIP (batch in eval mode, instance, none)")
         self.norm = norm
-        self.desc = EncoderDesc(int(output_dim), 1 if norm == "batch" else 0, int(cnet_dim))
+        self.desc = EncoderDesc(int(output_dim), {"none": 0, "batch": 1, "instance": 2}[norm], int(cnet_dim))
         n = int(lib.nnd_encoder_packed_floats(C.byref(self.desc)))
         if n <= 0:
             check(n, "encoder_packed_floats")

@@ -169,7 +169,7 @@ def test_encoder_pack_host(raft_sd):
     assert torch.equal(eng.packed[:64 * 147].view(64, 3, 7, 7), enc_sd["conv1.weight"])  # stem weights kept raw
     assert lib.nnd_encoder_workspace_floats(C.byref(eng.desc), 2, 544, 960) == 4 * 2 * 64 * 272 * 480
     with pytest.raises(NndError):
-        ops.EncoderEngine(256, "instance", 0)
+        ops.EncoderEngine(256, "group", 0)
     with pytest.raises(NndError):
         ops.EncoderEngine(256, "batch", 192).load(enc_sd, None, device="cpu")
 
@@ -185,7 +185,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     d = ConvDesc(16, 16, 3, 3, 3)
     assert lib.nnd_conv_packed_floats(C.byref(d)) < 0 and b"stride" in lib.nnd_last_error()
     assert lib.nnd_conv_forward(C.byref(ConvDesc(16, 16, 3, 3, 1)), None, None, None, None, 1, 8, 8, 0, 0, None) < 0
-    e = EncoderDesc(256, 2, 0)  # instance norm is not built
+    e = EncoderDesc(256, 3, 0)  # group norm is not built
     assert lib.nnd_encoder_packed_floats(C.byref(e)) < 0
     assert lib.nnd_encoder_forward(C.byref(EncoderDesc(256, 1, 0)), None, None, None, None, 0, None, 2, 64, 64, None) < 0
     u = UpdateBlockDesc(128, 128, 36, 2, 576, 0)

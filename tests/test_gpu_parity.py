@@ -688,3 +688,17 @@ def test_epe_parity_on_device(gold, raft_sd, tartanair_frames):
     ours = EvalCriterion({"d3": 3.0})(gt, up)
     ref = EvalCriterion({"d3": 3.0})(gt, t(g["up_disp_it32"]).to(DEV))
     assert abs(ours["epe"] - ref["epe"]) <= 1e-4 and abs(ours["d3"] - ref["d3"]) <= 1e-6
+
+
+def test_instance_norm_encoder_vs_oracle(cre_sd, CR):
+    """CREStereo's encoder (InstanceNorm2d(affine=False)) in HIP — raw convs, per-sample statistics, fused apply —
+    against the oracle restatement, at a size whose lower levels are ragged."""
+    from nndepth_amd import ops, weightgen
+    fr1, fr2 = weightgen.synthetic_frames(9, 1, 136, 200)
+    enc_sd = {k[len("fnet."):]: v for k, v in cre_sd.items() if k.startswith("fnet.")}
+    eng = ops.EncoderEngine(256, "instance", 0).load(enc_sd, None, device=DEV)
+    fm, _ = eng.forward(torch.cat([fr1, fr2], 0).to(DEV))
+    exp = CR.basic_encoder_in(cre_sd, "fnet", torch.cat([fr1, fr2], 0))
+    err = (fm.cpu() - exp).abs().max().item()
+    print(f"\ninstance-norm encoder 136x200: max-abs {err:.2e} (|fmap| max {exp.abs().max():.2f})")
+    assert err <= 5e-5
