@@ -214,6 +214,18 @@ int64_t nnd_epe_metrics_workspace_bytes(void);
 int nnd_epe_metrics(const float* disp_gt, const float* disp_pred, const unsigned char* valid_mask, int B, int C, int H, int W,
                     float max_flow, const float* thresholds_host, int num_thresholds, void* workspace, float* out, void* stream);
 
+/* ------------------------------------------------------------- LoFTR layer with linear attention (CREStereo)
+ * Replaces LoFTREncoderLayer.forward  nndepth/blocks/transformer.py:39-66 with LinearAttention  nndepth/blocks/attn_block.py:23-58
+ * (no masks).  The reference's (N, H*W, C) tokens are the (N,C,H,W) maps transposed, so every nn.Linear is a 1x1 conv of
+ * the map: x, source, out are (N, d_model, H, W); out = x + norm2(mlp([x | norm1(merge(attention(x, source)))])).
+ * d_model / nhead must be 32.  nnd_loftr_pack (HOST): tensors = q_proj.weight, k_proj.weight, v_proj.weight,
+ * merge.weight, mlp.0.weight, mlp.2.weight, norm1.weight, norm1.bias, norm2.weight, norm2.bias (state_dict order).      */
+int64_t nnd_loftr_packed_floats(int d_model, int nhead);
+int64_t nnd_loftr_workspace_floats(int d_model, int nhead, int N, int H, int W);
+int nnd_loftr_pack(int d_model, int nhead, const float* const* tensors_host, float* packed_host);
+int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed_dev, const float* x, const float* source, float* out,
+                            float* workspace, int N, int H, int W, void* stream);
+
 /* Fused tail of the mask head + convex upsample (the (B, 9*rate^2, H, W) mask is never written):
  *   out = convex_upsample(flow, 0.25 * conv1x1(x; W, b))      x (B,Cin,H,W), flow (B,1,H,W), out (B,1,rate*H,rate*W)
  * Replaces update_block.py:97-101,111 (mask.2, x0.25) + raft_stereo/model.py:93-105.  `packed_dev` is the blob of

@@ -72,6 +72,10 @@ SIGNATURES = {
     "nnd_replicate_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_epe_metrics_workspace_bytes": (C.c_int64, []),
     "nnd_epe_metrics": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_float, C.POINTER(C.c_float), _I, _P, _P, _P]),
+    "nnd_loftr_packed_floats": (C.c_int64, [_I, _I]),
+    "nnd_loftr_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "nnd_loftr_pack": (_I, [_I, _I, C.POINTER(_P), _P]),
+    "nnd_loftr_layer_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
                               C.POINTER(C.c_double)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),

@@ -103,6 +103,9 @@ class AGCL:
         on the same two maps in every iteration; at inference the result is the same each time, so it is cached."""
         if self.att is None:
             return self.fmap1, self.fmap2
+        if self._attended is None and hasattr(self.att, "forward_maps"):
+            a, b = self.att.forward_maps(self.fmap1, self.fmap2)  # map-level API of nndepth_amd's transformer: no transposes
+            self._attended = (a.float().contiguous(), b.float().contiguous())
         if self._attended is None:
             N, C, H, W = self.fmap1.shape
             a = self.fmap1.permute(0, 2, 3, 1).reshape(N, H * W, C)

@@ -63,23 +63,46 @@ class LoFTREncoderLayer(nn.Module):
 
 
 class LocalFeatureTransformer(nn.Module):
+    """`forward(feat0, feat1)` takes (N, L, C) tokens like the reference (PyTorch path).  `forward_maps(map0, map1)` is the
+    same computation on (N, C, H, W) maps — the tokens transposed — and runs in HIP (csrc/loftr.hip: every Linear is a 1x1
+    conv of the map, the linear attention and the LayerNorms are small kernels); CREStereoBase and AGCL use it on the GPU."""
+
     def __init__(self, d_model: int, nhead: int, layer_names, attention: str = "linear"):
         super().__init__()
         if attention != "linear":
             raise ValueError("only the linear attention of CREStereo is provided")
-        self.d_model, self.layer_names = d_model, list(layer_names)
+        self.d_model, self.nhead, self.layer_names = d_model, nhead, list(layer_names)
         self.layers = nn.ModuleList([LoFTREncoderLayer(d_model, nhead) for _ in self.layer_names])
+        self._engines, self._version = None, None
 
-    def forward(self, feat0: torch.Tensor, feat1: torch.Tensor):
-        for layer, name in zip(self.layers, self.layer_names):
+    def _layer_step(self, run, feat0, feat1):
+        for i, name in enumerate(self.layer_names):
             if name == "self":
-                feat0, feat1 = layer(feat0, feat0), layer(feat1, feat1)
+                feat0, feat1 = run(i, feat0, feat0), run(i, feat1, feat1)
             elif name == "cross":
-                feat0 = layer(feat0, feat1)
-                feat1 = layer(feat1, feat0)  # sees the updated feat0, like the reference
+                feat0 = run(i, feat0, feat1)
+                feat1 = run(i, feat1, feat0)  # sees the updated feat0, like the reference
             else:
                 raise KeyError(name)
         return feat0, feat1
+
+    def forward(self, feat0: torch.Tensor, feat1: torch.Tensor):
+        return self._layer_step(lambda i, a, b: self.layers[i](a, b), feat0, feat1)
+
+    def hip_ready(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and not self.training and self.d_model // self.nhead == 32
+
+    def forward_maps(self, map0: torch.Tensor, map1: torch.Tensor):
+        if not self.hip_ready(map0):
+            n, c, h, w = map0.shape
+            a, b = self.forward(map0.permute(0, 2, 3, 1).reshape(n, h * w, c), map1.permute(0, 2, 3, 1).reshape(n, h * w, c))
+            return a.reshape(n, h, w, c).permute(0, 3, 1, 2), b.reshape(n, h, w, c).permute(0, 3, 1, 2)
+        v = (tuple((p.data_ptr(), p._version) for p in self.parameters()), str(map0.device))
+        if v != self._version:
+            self._engines = [ops.LoftrEngine(self.d_model, self.nhead).load(layer.state_dict(), device=map0.device)
+                             for layer in self.layers]
+            self._version = v
+        return self._layer_step(lambda i, a, b: self._engines[i].forward(a.float(), b.float()), map0, map1)
 
 
 def position_encoding_sine(d_model: int, h: int, w: int, device) -> torch.Tensor:
@@ -184,11 +207,7 @@ class CREStereoBase(nn.Module):
             n, c, h16, w16 = f1_16.shape
             pe = position_encoding_sine(c, frame1.shape[2] // (ds * 4), frame1.shape[3] // (ds * 4), f1_16.device)
             pe = pe[:, :, :h16, :w16]
-            t1 = (f1_16 + pe).permute(0, 2, 3, 1).reshape(n, h16 * w16, c)
-            t2 = (f2_16 + pe).permute(0, 2, 3, 1).reshape(n, h16 * w16, c)
-            t1, t2 = self.self_att_fn(t1, t2)
-            f1_16 = t1.reshape(n, h16, w16, c).permute(0, 3, 1, 2)
-            f2_16 = t2.reshape(n, h16, w16, c).permute(0, 3, 1, 2)
+            f1_16, f2_16 = self.self_att_fn.forward_maps(f1_16 + pe, f2_16 + pe)
             flow16 = torch.zeros(n, 2, h16, w16, dtype=torch.float32, device=fmap1.device)
             _, _, up = self._stage(self.corr_cls(f1_16, f2_16, att=self.cross_att_fn), net16, inp16, flow16, off16,
                                    self.iters // 2, False, outs)

@@ -503,3 +503,45 @@ def softargmin_disparity(logits: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(d):
         check(lib.nnd_softargmin_disparity(_p(logits), _p(out), B, D, H, W, _stream(d)), "softargmin_disparity")
     return out
+
+
+LOFTR_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
+              "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+class LoftrEngine:
+    """One LoFTR encoder layer (linear attention) on (N, d_model, H, W) maps (csrc/loftr.hip)."""
+
+    def __init__(self, d_model: int, nhead: int):
+        self.d_model, self.nhead = int(d_model), int(nhead)
+        n = int(lib.nnd_loftr_packed_floats(self.d_model, self.nhead))
+        if n <= 0:
+            check(n, "loftr_packed_floats")
+        self.packed_floats = n
+        self.packed = None
+        self._ws = None
+
+    def load(self, sd, prefix: str = "", device="cuda") -> "LoftrEngine":
+        host = [_host(sd[prefix + k]) for k in LOFTR_KEYS]
+        arr = (C.c_void_p * len(host))(*[t.data_ptr() for t in host])
+        blob = torch.empty(self.packed_floats, dtype=torch.float32)
+        check(lib.nnd_loftr_pack(self.d_model, self.nhead, arr, _p(blob)), "loftr_pack")
+        self.packed = blob.to(device)
+        return self
+
+    def forward(self, x: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+        if self.packed is None:
+            raise NndError("LoftrEngine: parameters not loaded")
+        d = _dev(x, source, self.packed)
+        x, source = x.contiguous(), source.contiguous()
+        N, Cc, H, W = x.shape
+        if Cc != self.d_model or source.shape != x.shape:
+            raise NndError(f"loftr: x {tuple(x.shape)} / source {tuple(source.shape)} must both be (N, {self.d_model}, H, W)")
+        need = int(lib.nnd_loftr_workspace_floats(self.d_model, self.nhead, N, H, W))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != d:
+            self._ws = torch.empty(need, dtype=torch.float32, device=d)
+        out = torch.empty_like(x)
+        with torch.cuda.device(d):
+            check(lib.nnd_loftr_layer_forward(self.d_model, self.nhead, _p(self.packed), _p(x), _p(source), _p(out), _p(self._ws),
+                                              N, H, W, _stream(d)), "loftr_layer_forward")
+        return out

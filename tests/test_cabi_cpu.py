@@ -191,3 +191,17 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     u = UpdateBlockDesc(128, 128, 36, 2, 576, 0)
     assert lib.nnd_cre_stereo_refine(C.byref(u), None, None, None, 256, None, None, None, None, None, None, 0, None, None, None,
                                      1, 8, 8, 8, 2, None) < 0
+
+
+def test_loftr_pack_host(cre_sd):
+    from nndepth_amd import ops
+    from nndepth_amd._lib import lib, NndError
+    eng = ops.LoftrEngine(256, 8).load(cre_sd, "self_att_fn.layers.0.", device="cpu")
+    assert eng.packed.numel() == eng.packed_floats and torch.isfinite(eng.packed).all()
+    C_ = 256
+    assert torch.equal(eng.packed[-4 * C_:-3 * C_], cre_sd["self_att_fn.layers.0.norm1.weight"])
+    assert torch.equal(eng.packed[-C_:], cre_sd["self_att_fn.layers.0.norm2.bias"])
+    assert lib.nnd_loftr_workspace_floats(256, 8, 1, 33, 60) > 6 * 256 * 33 * 60
+    with pytest.raises(NndError):
+        ops.LoftrEngine(256, 4)  # 64 channels per head: the attention kernels are built for 32
+    assert lib.nnd_loftr_layer_forward(256, 8, None, None, None, None, None, 1, 8, 8, None) < 0

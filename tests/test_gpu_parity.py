@@ -702,3 +702,36 @@ def test_instance_norm_encoder_vs_oracle(cre_sd, CR):
     err = (fm.cpu() - exp).abs().max().item()
     print(f"\ninstance-norm encoder 136x200: max-abs {err:.2e} (|fmap| max {exp.abs().max():.2f})")
     assert err <= 5e-5
+
+
+# ------------------------------------------------------------ LoFTR layer with linear attention
+@pytest.mark.parametrize("H,W,N", [(33, 60, 1), (17, 30, 2), (5, 8, 1)])
+def test_loftr_layer_vs_oracle(cre_sd, CR, H, W, N):
+    """One LoFTR encoder layer in HIP on (N,256,H,W) maps against the oracle's token-level restatement (pinned to the
+    reference through tests/golden/cre_agcl.npz / cre_forward.npz), self- and cross-style inputs."""
+    from nndepth_amd import ops
+    torch.manual_seed(H * W)
+    p = "cross_att_fn.layers.0"
+    eng = ops.LoftrEngine(256, 8).load(cre_sd, p + ".", device=DEV)
+    x, src = torch.randn(N, 256, H, W), torch.randn(N, 256, H, W)
+    tok = lambda m: m.permute(0, 2, 3, 1).reshape(N, H * W, 256)
+    for a, b in ((x, src), (x, x)):
+        exp = CR.loftr_layer(cre_sd, p, tok(a), tok(b)).reshape(N, H, W, 256).permute(0, 3, 1, 2)
+        got = eng.forward(a.to(DEV), b.to(DEV)).cpu()
+        assert (got - exp).abs().max() <= 3e-5 * max(1.0, exp.abs().max().item())
+
+
+def test_cre_transformer_maps_path_matches_token_path(cre_sd):
+    from nndepth_amd.cre_stereo import CREStereoBase
+    m = CREStereoBase(iters=2)
+    m.load_state_dict(cre_sd, strict=True)
+    m = m.to(DEV).eval()
+    torch.manual_seed(3)
+    a, b = torch.randn(1, 256, 9, 14, device=DEV), torch.randn(1, 256, 9, 14, device=DEV)
+    tok = lambda t_: t_.permute(0, 2, 3, 1).reshape(1, 9 * 14, 256)
+    for tr in (m.self_att_fn, m.cross_att_fn):
+        h0, h1 = tr.forward_maps(a, b)                       # HIP
+        with torch.no_grad():
+            t0, t1 = tr(tok(a), tok(b))                      # PyTorch modules (reference formulation)
+        for hmap, ttok in ((h0, t0), (h1, t1)):
+            assert (tok(hmap) - ttok).abs().max() <= 5e-5
