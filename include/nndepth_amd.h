@@ -226,6 +226,24 @@ int nnd_loftr_pack(int d_model, int nhead, const float* const* tensors_host, flo
 int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed_dev, const float* x, const float* source, float* out,
                             float* workspace, int N, int H, int W, void* stream);
 
+/* ------------------------------------------------------------- 3x3x3 Conv3d (IGEV cost-volume regulariser, row a15)
+ * ConvBn3D / the conv of Upsampler3D:  nndepth/models/igev_stereo/cost_volume.py:101-130
+ *   y = LeakyReLU_slope( BatchNorm3d_eval( conv3d(cat(x0, x1); w, stride, padding 1) + bias ) )        (norm / bias optional)
+ * Volumes are DEPTH-MAJOR, (N, D+2, C, H, W) with one zero slice before and after the D real ones
+ * (nnd_volume_to_depth_major / nnd_depth_major_to_volume convert from / to the usual (N, C, D, H, W)); a Conv3d is then one
+ * launch of the 2-D MFMA convolution per sample over 3*C consecutive planes (csrc/conv3d.hip).  Cin1 = 0: single input.
+ * nnd_conv3d_pack (HOST): w (Cout, Cin0+Cin1, 3, 3, 3), bias / bn_* may be NULL.  leaky_slope 1 = no activation.          */
+typedef struct nnd_conv3d_desc {
+    int Cout, Cin0, Cin1, stride;
+} nnd_conv3d_desc;
+int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc);
+int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w_host, const float* bias_host, const float* bn_gamma,
+                    const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, float* packed_host);
+int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed_dev, const float* x0, const float* x1, float* y,
+                       int N, int D, int H, int W, float leaky_slope, void* stream);
+int nnd_volume_to_depth_major(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
+int nnd_depth_major_to_volume(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
+
 /* Fused tail of the mask head + convex upsample (the (B, 9*rate^2, H, W) mask is never written):
  *   out = convex_upsample(flow, 0.25 * conv1x1(x; W, b))      x (B,Cin,H,W), flow (B,1,H,W), out (B,1,rate*H,rate*W)
  * Replaces update_block.py:97-101,111 (mask.2, x0.25) + raft_stereo/model.py:93-105.  `packed_dev` is the blob of

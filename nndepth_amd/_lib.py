@@ -23,6 +23,10 @@ class ConvDesc(C.Structure):
     _fields_ = [("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32)]
 
 
+class Conv3dDesc(C.Structure):
+    _fields_ = [("Cout", C.c_int32), ("Cin0", C.c_int32), ("Cin1", C.c_int32), ("stride", C.c_int32)]
+
+
 class EncoderDesc(C.Structure):
     _fields_ = [("output_dim", C.c_int32), ("norm", C.c_int32), ("cnet_dim", C.c_int32)]
 
@@ -76,6 +80,11 @@ SIGNATURES = {
     "nnd_loftr_workspace_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "nnd_loftr_pack": (_I, [_I, _I, C.POINTER(_P), _P]),
     "nnd_loftr_layer_forward": (_I, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "nnd_conv3d_packed_floats": (C.c_int64, [C.POINTER(Conv3dDesc)]),
+    "nnd_conv3d_pack": (_I, [C.POINTER(Conv3dDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P]),
+    "nnd_conv3d_forward": (_I, [C.POINTER(Conv3dDesc), _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P]),
+    "nnd_volume_to_depth_major": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_depth_major_to_volume": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
                               C.POINTER(C.c_double)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),

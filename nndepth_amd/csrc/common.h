@@ -80,7 +80,7 @@ struct ConvIO {
     int hidden = 0;
     float scale = 1.f;
     int Hin = 0, Win = 0;  // input size when it differs from the output size (stride 2); 0: same
-    int flags = 0;         // EPI_AFFINE flags
+    int flags = 0;         // EPI_AFFINE flags: 1 ReLU, 2 ReLU after the residual, 4 LeakyReLU with slope `scale`
     bool src_tiled = false;  // layout.h: sources are tile-major (internal workspace) instead of NCHW
     bool dst_tiled = false;  // ... out0/out1/aux0/aux1/bmap
 };

@@ -82,7 +82,8 @@ struct ConvArgs {
     int H, W, Cout, nchunks, epi, hidden;  // H, W: OUTPUT size
     int Hin, Win;                          // input size (== H, W for stride 1)
     int tiles_x, wco, ks, npos, ngroups;
-    int flags;                             // EPI_AFFINE: bit 0 ReLU after the affine, bit 1 ReLU after the residual add
+    int flags;                             // EPI_AFFINE: bit 0 ReLU after the affine, bit 1 ReLU after the residual add,
+                                           // bit 2 LeakyReLU (negative slope = scale) after the affine
     const float* cscale;                   // EPI_AFFINE: per-channel scale (folded norm), shift comes in through `bias`
     float scale;
 };
@@ -408,6 +409,7 @@ conv_mfma_kernel(ConvArgs a) {
                 a.out0[b * a.obs0 + co * DP + pix] = a.scale * v;
             } else if (epi == EPI_AFFINE) {  // folded norm: y = acc*scale + shift; optional ReLU, residual add, ReLU
                 float y2 = fmaf(acc[pp][reg], z_r[reg], bias_r[reg]);
+                if (a.flags & 4) y2 = y2 > 0.f ? y2 : a.scale * y2;  // LeakyReLU (slope in `scale`), Conv3d path
                 if (a.flags & 1) y2 = fmaxf(y2, 0.f);
                 if (a.aux0) y2 = h_r[reg] + y2;
                 if (a.flags & 2) y2 = fmaxf(y2, 0.f);

@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import ConvDesc, EncoderDesc, NndError, UpdateBlockDesc, check, lib
+from ._lib import Conv3dDesc, ConvDesc, EncoderDesc, NndError, UpdateBlockDesc, check, lib
 
 
 def _dev(*tensors: torch.Tensor) -> torch.device:
@@ -545,3 +545,67 @@ class LoftrEngine:
             check(lib.nnd_loftr_layer_forward(self.d_model, self.nhead, _p(self.packed), _p(x), _p(source), _p(out), _p(self._ws),
                                               N, H, W, _stream(d)), "loftr_layer_forward")
         return out
+
+
+# ------------------------------------------------------------------ Conv3d on depth-major volumes (IGEV regulariser, a15)
+def volume_to_depth_major(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,D,H,W) -> (N,D+2,C,H,W) with zero end slices."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Cc, D, H, W = x.shape
+    y = torch.empty((N, D + 2, Cc, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_volume_to_depth_major(_p(x), _p(y), N, Cc, D, H, W, _stream(d)), "volume_to_depth_major")
+    return y
+
+
+def depth_major_to_volume(x: torch.Tensor) -> torch.Tensor:
+    """(N,D+2,C,H,W) -> (N,C,D,H,W)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Dp, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, Dp - 2, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_depth_major_to_volume(_p(x), _p(y), N, Cc, Dp - 2, H, W, _stream(d)), "depth_major_to_volume")
+    return y
+
+
+class Conv3dNorm:
+    """nn.Conv3d(k=3, padding=1, stride 1|2) [+ BatchNorm3d(eval)] [+ LeakyReLU] on depth-major volumes; the input may be the
+    channel concat of two volumes.  `bn` = (weight, bias, running_mean, running_var) or None."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, bn=None, eps: float = 1e-5,
+                 leaky_slope: float = 1.0, split: int = 0, device="cuda"):
+        Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
+        if tuple(weight.shape[2:]) != (3, 3, 3):
+            raise NndError("Conv3dNorm: only 3x3x3 kernels")
+        cin0 = split if split > 0 else Cin
+        self.desc = Conv3dDesc(Cout, cin0, Cin - cin0, int(stride))
+        self.leaky = float(leaky_slope)
+        n = int(lib.nnd_conv3d_packed_floats(C.byref(self.desc)))
+        if n <= 0:
+            check(n, "conv3d_packed_floats")
+        w, b = _host(weight), _host(bias)
+        g, be, m, v = (_host(t) for t in bn) if bn is not None else (None, None, None, None)
+        blob = torch.empty(n, dtype=torch.float32)
+        check(lib.nnd_conv3d_pack(C.byref(self.desc), _p(w), _p(b), _p(g), _p(be), _p(m), _p(v), float(eps), _p(blob)), "conv3d_pack")
+        self.packed = blob.to(device)
+
+    def __call__(self, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+        d = _dev(x0, self.packed)
+        x0 = x0.contiguous()
+        N, Dp, c0, H, W = x0.shape
+        if c0 != self.desc.Cin0 or (self.desc.Cin1 > 0) != (x1 is not None):
+            raise NndError(f"conv3d: inputs do not match the layer ({c0} vs {self.desc.Cin0} channels, second input {x1 is not None})")
+        if x1 is not None:
+            x1 = x1.contiguous()
+            _dev(x1)
+            if tuple(x1.shape) != (N, Dp, self.desc.Cin1, H, W):
+                raise NndError(f"conv3d: second input {tuple(x1.shape)} != {(N, Dp, self.desc.Cin1, H, W)}")
+        st, D = self.desc.stride, Dp - 2
+        Do, Ho, Wo = (D + st - 1) // st, (H + st - 1) // st, (W + st - 1) // st
+        y = torch.empty((N, Do + 2, self.desc.Cout, Ho, Wo), dtype=torch.float32, device=d)
+        with torch.cuda.device(d):
+            check(lib.nnd_conv3d_forward(C.byref(self.desc), _p(self.packed), _p(x0), _p(x1), _p(y), N, D, H, W, self.leaky,
+                                         _stream(d)), "conv3d_forward")
+        return y

@@ -735,3 +735,26 @@ def test_cre_transformer_maps_path_matches_token_path(cre_sd):
             t0, t1 = tr(tok(a), tok(b))                      # PyTorch modules (reference formulation)
         for hmap, ttok in ((h0, t0), (h1, t1)):
             assert (tok(hmap) - ttok).abs().max() <= 5e-5
+
+
+# ------------------------------------------------------------ Conv3d on depth-major volumes (IGEV regulariser, a15)
+@pytest.mark.parametrize("Cout,Cin,split,stride,N,D,H,W", [
+    (8, 8, 0, 1, 1, 12, 9, 14), (8, 16, 0, 1, 2, 7, 10, 12), (16, 8, 0, 2, 1, 12, 10, 16), (32, 16, 0, 2, 1, 7, 9, 11),
+    (16, 32, 16, 1, 1, 6, 8, 10), (32, 64, 32, 1, 1, 5, 6, 9), (64, 64, 0, 1, 1, 4, 5, 8)])
+def test_conv3d_norm_vs_torch(ops, Cout, Cin, split, stride, N, D, H, W):
+    """ConvBn3D of the IGEV regulariser (Conv3d k3 p1, stride 1/2, BatchNorm3d eval, LeakyReLU 0.01), also on a channel
+    concat of two volumes, against the same PyTorch CPU ops; layout round trip included."""
+    torch.manual_seed(Cout * 100 + Cin + stride)
+    w = torch.randn(Cout, Cin, 3, 3, 3) * (2.0 / (Cin * 27)) ** 0.5
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5)
+    x = torch.randn(N, Cin, D, H, W)
+    ref = torch.nn.functional.conv3d(x, w, None, stride=stride, padding=1)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5), 0.01)
+    conv = ops.Conv3dNorm(w, None, stride, bn, 1e-5, 0.01, split, DEV)
+    if split:
+        y = conv(ops.volume_to_depth_major(x[:, :split].to(DEV)), ops.volume_to_depth_major(x[:, split:].to(DEV)))
+    else:
+        y = conv(ops.volume_to_depth_major(x.to(DEV)))
+    assert y[:, 0].abs().max() == 0 and y[:, -1].abs().max() == 0  # the zero end slices the next layer relies on
+    got = ops.depth_major_to_volume(y).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max() <= 3e-5
