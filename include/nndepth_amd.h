@@ -243,6 +243,11 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed_dev, con
                        int N, int D, int H, int W, float leaky_slope, void* stream);
 int nnd_volume_to_depth_major(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
 int nnd_depth_major_to_volume(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
+/* Upsampler3D's F.interpolate(scale_factor=2, mode="trilinear", align_corners=True) (cost_volume.py:128): depth-major
+ * x (N,D+2,C,H,W) -> y (N,2D+2,C,2H,2W).  FeatureGuidedBlock (cost_volume.py:133-147): vol *= sigmoid(logits (N,C,H,W)),
+ * broadcast over the depth slices, in place.                                                                              */
+int nnd_volume_upsample2x(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
+int nnd_volume_gate(float* vol, const float* logits, int N, int C, int D, int H, int W, void* stream);
 
 /* Fused tail of the mask head + convex upsample (the (B, 9*rate^2, H, W) mask is never written):
  *   out = convex_upsample(flow, 0.25 * conv1x1(x; W, b))      x (B,Cin,H,W), flow (B,1,H,W), out (B,1,rate*H,rate*W)

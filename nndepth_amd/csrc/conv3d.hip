@@ -15,17 +15,26 @@
 
 namespace nnd {
 
-static int conv3d_layer(const nnd_conv3d_desc* d, ConvLayer* L, int64_t* total) {
+// Thin layers (Cout 8 / 16 use only a quarter / half of the 32 MFMA rows): J adjacent output slices are computed by one
+// launch element — their (J+2)-slice input windows overlap, so they become J*Cout output channels of a conv over
+// (J+2)*Cin planes whose weights are zero where tap kd - j falls outside 0..2.  Half the K is zeros for J = 4, but the
+// rows are full: 2x fewer MFMAs for Cout = 8, 1.5x fewer for Cout = 16.  Stride 1 only; needs D % J == 0.
+static int group_of(const nnd_conv3d_desc* d) {
+    if (d->stride != 1) return 1;
+    return d->Cout <= 8 ? 4 : (d->Cout <= 16 ? 2 : 1);
+}
+
+static int conv3d_layer(const nnd_conv3d_desc* d, int J, ConvLayer* L, int64_t* total) {
     NND_REQUIRE(d, "conv3d: null descriptor");
     NND_REQUIRE(d->Cout > 0 && d->Cin0 > 0 && d->Cin1 >= 0, "conv3d: bad channel counts");
     NND_REQUIRE(d->stride == 1 || d->stride == 2, "conv3d: stride %d not supported (1, 2)", d->stride);
     ConvLayer l;
     l.KH = l.KW = 3;
-    l.Cin = 3 * (d->Cin0 + d->Cin1);
-    l.Cout = d->Cout;
+    l.Cin = (J + 2) * (d->Cin0 + d->Cin1);
+    l.Cout = J * d->Cout;
     l.stride = d->stride;
     l.CI_T = 16;  // windows of 3*Cin planes: 24, 48, 96, 192 -> 16-channel chunks keep the two sources chunk-aligned
-    NND_REQUIRE(d->Cin1 == 0 || (3 * d->Cin0) % l.CI_T == 0, "conv3d: first input of a concat needs 3*Cin0 %% 16 == 0 (Cin0 = %d)", d->Cin0);
+    NND_REQUIRE(d->Cin1 == 0 || ((J + 2) * d->Cin0) % l.CI_T == 0, "conv3d: first input of a concat needs (J+2)*Cin0 %% 16 == 0 (Cin0 = %d)", d->Cin0);
     l.nchunks = cdiv(l.Cin, l.CI_T);
     l.ncb = cdiv(l.Cout, 32);
     int64_t off = 0;
@@ -56,6 +65,56 @@ __global__ void __launch_bounds__(256) from_depth_major_kernel(const float* __re
     dst[(((long)n * C + c) * D + d) * HW + i] = src[(((long)n * (D + 2) + d + 1) * C + c) * HW + i];
 }
 
+
+// ATen compute_source_index_and_lambda for align_corners = true: real = scale * dst, scale = (in - 1) / (out - 1)
+__device__ __forceinline__ void src_index_ac(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    const float real = scale * (float)dst;
+    i0 = min((int)floorf(real), in_size - 1);
+    l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l0 = 1.f - l1;
+}
+
+// F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True) of Upsampler3D (cost_volume.py:128) on depth-major
+// volumes: x (N, D+2, C, H, W) -> y (N, 2D+2, C, 2H, 2W) incl. its zero end slices.  One thread per output element of a plane.
+__global__ void __launch_bounds__(256) trilinear_up2_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int D, int H,
+                                                            int W) {
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Ho * Wo) return;
+    const int c = blockIdx.y % C, dp = blockIdx.y / C, n = blockIdx.z;  // dp: padded output slice 0..Do+1
+    float* o = y + (((long)n * (Do + 2) + dp) * C + c) * Ho * Wo + i;
+    if (dp == 0 || dp == Do + 1) {
+        *o = 0.f;
+        return;
+    }
+    const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
+    int d0, d1, y0, y1, x0, x1;
+    float ld0, ld1, ly0, ly1, lx0, lx1;
+    src_index_ac(Do > 1 ? (float)(D - 1) / (float)(Do - 1) : 0.f, dp - 1, D, d0, d1, ld0, ld1);
+    src_index_ac(Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, oy, H, y0, y1, ly0, ly1);
+    src_index_ac(Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, ox, W, x0, x1, lx0, lx1);
+    const long HW = (long)H * W;
+    const float* p0 = x + (((long)n * (D + 2) + d0 + 1) * C + c) * HW;
+    const float* p1 = x + (((long)n * (D + 2) + d1 + 1) * C + c) * HW;
+    auto plane = [&](const float* p) {
+        const float t0 = lx0 * p[(long)y0 * W + x0] + lx1 * p[(long)y0 * W + x1];
+        const float t1 = lx0 * p[(long)y1 * W + x0] + lx1 * p[(long)y1 * W + x1];
+        return ly0 * t0 + ly1 * t1;
+    };
+    *o = ld0 * plane(p0) + ld1 * plane(p1);
+}
+
+// FeatureGuidedBlock (cost_volume.py:133-147): vol[n, d, c, h, w] *= sigmoid(logit[n, c, h, w]) for every depth slice, in place
+__global__ void __launch_bounds__(256) gate_kernel(float* __restrict__ vol, const float* __restrict__ logit, int C, int D, long HW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float g = 1.0f / (1.0f + expf(-logit[((long)n * C + c) * HW + i]));
+    float* p = vol + (((long)n * (D + 2) + 1) * C + c) * HW + i;
+    for (int d = 0; d < D; ++d) p[(long)d * C * HW] *= g;
+}
+
 }  // namespace nnd
 
 using namespace nnd;
@@ -64,48 +123,64 @@ extern "C" {
 
 int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
     ConvLayer L;
-    int64_t total;
-    if (conv3d_layer(desc, &L, &total) != NND_OK) return NND_ERR_INVALID;
-    return total;
+    int64_t t1, tj = 0;
+    if (conv3d_layer(desc, 1, &L, &t1) != NND_OK) return NND_ERR_INVALID;
+    const int J = group_of(desc);
+    if (J > 1 && conv3d_layer(desc, J, &L, &tj) != NND_OK) return NND_ERR_INVALID;
+    return t1 + tj;  // [plain layer | J-slice grouped layer]
 }
 
-// w (Cout, Cin0+Cin1, 3, 3, 3) [kd, kh, kw]; bias may be NULL (the reference's ConvBn3D has bias=False); bn_* may be NULL
-int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bias, const float* bn_gamma, const float* bn_beta,
-                    const float* bn_mean, const float* bn_var, float bn_eps, float* packed_host) {
-    ConvLayer L;
-    int rc = conv3d_layer(desc, &L, nullptr);
-    if (rc != NND_OK) return rc;
-    NND_REQUIRE(w && packed_host, "conv3d_pack: null pointer");
-    NND_REQUIRE(!bn_gamma || (bn_beta && bn_mean && bn_var), "conv3d_pack: incomplete batch-norm parameters");
-    const int C0 = desc->Cin0, C1 = desc->Cin1, Ct = C0 + C1, Co = desc->Cout;
-    // 2-D weight (Cout, 3*Ct, 3, 3): channel order = [window of input 0: kd-major, ci] [window of input 1: kd-major, ci]
-    std::vector<float> w2((size_t)Co * 3 * Ct * 9);
-    for (int co = 0; co < Co; ++co)
-        for (int ci = 0; ci < Ct; ++ci)
-            for (int kd = 0; kd < 3; ++kd) {
-                const int c2 = ci < C0 ? kd * C0 + ci : 3 * C0 + kd * C1 + (ci - C0);
-                for (int t = 0; t < 9; ++t)
-                    w2[((size_t)co * 3 * Ct + c2) * 9 + t] = w[(((size_t)co * Ct + ci) * 3 + kd) * 9 + t];
-            }
+// 2-D weights of the J-slice grouped layer: (J*Cout, (J+2)*Ct, 3, 3) with [window of input 0: slice-major, ci][window of input 1]
+static void pack_one(const nnd_conv3d_desc* desc, const ConvLayer& L, int J, const float* w, const float* bias, const float* g,
+                     const float* be, const float* mean, const float* var, float eps, float* base) {
+    const int C0 = desc->Cin0, C1 = desc->Cin1, Ct = C0 + C1, Co = desc->Cout, S = J + 2;
+    std::vector<float> w2((size_t)J * Co * S * Ct * 9, 0.f);
+    for (int j = 0; j < J; ++j)
+        for (int co = 0; co < Co; ++co)
+            for (int ci = 0; ci < Ct; ++ci)
+                for (int kd = 0; kd < 3; ++kd) {
+                    const int sl = j + kd;  // slice of the window this tap reads
+                    const int c2 = ci < C0 ? sl * C0 + ci : S * C0 + sl * C1 + (ci - C0);
+                    for (int t = 0; t < 9; ++t)
+                        w2[((size_t)(j * Co + co) * S * Ct + c2) * 9 + t] = w[(((size_t)co * Ct + ci) * 3 + kd) * 9 + t];
+                }
     const float* ws[1] = {w2.data()};
     const float* bs[1] = {nullptr};
-    int cc[1] = {Co};
-    pack_conv(L, 1, ws, bs, cc, packed_host);
-    float* shift = packed_host + L.b_off;
-    float* scale = packed_host + L.s_off;
+    int cc[1] = {J * Co};
+    pack_conv(L, 1, ws, bs, cc, base);
+    float* shift = base + L.b_off;
+    float* scale = base + L.s_off;
     for (int c = 0; c < L.ncb * 32; ++c) {
         double sc = 1.0, sh = 0.0;
-        if (c < Co) {
-            const double b = bias ? (double)bias[c] : 0.0;
-            if (bn_gamma) {
-                sc = (double)bn_gamma[c] / std::sqrt((double)bn_var[c] + (double)bn_eps);
-                sh = (b - (double)bn_mean[c]) * sc + (double)bn_beta[c];
+        if (c < J * Co) {
+            const int co = c % Co;
+            const double b = bias ? (double)bias[co] : 0.0;
+            if (g) {
+                sc = (double)g[co] / std::sqrt((double)var[co] + (double)eps);
+                sh = (b - (double)mean[co]) * sc + (double)be[co];
             } else {
                 sh = b;
             }
         }
         scale[c] = (float)sc;
         shift[c] = (float)sh;
+    }
+}
+
+// w (Cout, Cin0+Cin1, 3, 3, 3) [kd, kh, kw]; bias may be NULL (the reference's ConvBn3D has bias=False); bn_* may be NULL
+int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bias, const float* bn_gamma, const float* bn_beta,
+                    const float* bn_mean, const float* bn_var, float bn_eps, float* packed_host) {
+    ConvLayer L1, LJ;
+    int64_t t1;
+    int rc = conv3d_layer(desc, 1, &L1, &t1);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(w && packed_host, "conv3d_pack: null pointer");
+    NND_REQUIRE(!bn_gamma || (bn_beta && bn_mean && bn_var), "conv3d_pack: incomplete batch-norm parameters");
+    pack_one(desc, L1, 1, w, bias, bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, packed_host);
+    const int J = group_of(desc);
+    if (J > 1) {
+        if ((rc = conv3d_layer(desc, J, &LJ, nullptr)) != NND_OK) return rc;
+        pack_one(desc, LJ, J, w, bias, bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, packed_host + t1);
     }
     return NND_OK;
 }
@@ -115,13 +190,21 @@ int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bi
 int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const float* x0, const float* x1, float* y, int N, int D,
                        int H, int W, float leaky_slope, void* stream) {
     ConvLayer L;
-    int rc = conv3d_layer(desc, &L, nullptr);
+    int64_t t1;
+    int rc = conv3d_layer(desc, 1, &L, &t1);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && x0 && y && (desc->Cin1 == 0 || x1), "conv3d_forward: null pointer");
     NND_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_forward: bad shape");
+    int J = group_of(desc);
+    if (D % J != 0) J = 1;  // the grouped layer needs whole groups of slices; the plain one is always packed as well
+    const float* blob = packed;
+    if (J > 1) {
+        if ((rc = conv3d_layer(desc, J, &L, nullptr)) != NND_OK) return rc;
+        blob = packed + t1;
+    }
     const int st = desc->stride;
     const int Do = (D + st - 1) / st, Ho = (H + st - 1) / st, Wo = (W + st - 1) / st;
-    NND_REQUIRE(Do <= 65535, "conv3d_forward: depth %d exceeds the grid limit", Do);
+    NND_REQUIRE(Do / J <= 65535, "conv3d_forward: depth %d exceeds the grid limit", Do);
     hipStream_t s = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W, hwo = (int64_t)Ho * Wo;
     for (int n = 0; n < N; ++n) {
@@ -129,15 +212,15 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
         NND_HIP_CHECK(hipMemsetAsync(yn, 0, sizeof(float) * desc->Cout * hwo, s));
         NND_HIP_CHECK(hipMemsetAsync(yn + (int64_t)(Do + 1) * desc->Cout * hwo, 0, sizeof(float) * desc->Cout * hwo, s));
         ConvIO io{};
-        // output slice d reads padded input slices st*d .. st*d+2 (= real slices st*d-1 .. st*d+1)
-        io.src0 = Act{const_cast<float*>(x0) + (int64_t)n * (D + 2) * desc->Cin0 * hw, (int64_t)st * desc->Cin0 * hw, 3 * desc->Cin0};
+        // launch element g computes output slices g*J .. g*J+J-1 from padded input slices st*g*J .. (+J+1)
+        io.src0 = Act{const_cast<float*>(x0) + (int64_t)n * (D + 2) * desc->Cin0 * hw, (int64_t)st * J * desc->Cin0 * hw, (J + 2) * desc->Cin0};
         if (desc->Cin1 > 0)
-            io.src1 = Act{const_cast<float*>(x1) + (int64_t)n * (D + 2) * desc->Cin1 * hw, (int64_t)st * desc->Cin1 * hw, 3 * desc->Cin1};
-        io.out0 = Act{yn + desc->Cout * hwo, (int64_t)desc->Cout * hwo, desc->Cout};
+            io.src1 = Act{const_cast<float*>(x1) + (int64_t)n * (D + 2) * desc->Cin1 * hw, (int64_t)st * J * desc->Cin1 * hw, (J + 2) * desc->Cin1};
+        io.out0 = Act{yn + desc->Cout * hwo, (int64_t)J * desc->Cout * hwo, J * desc->Cout};
         io.Hin = H; io.Win = W;
         io.flags = leaky_slope != 1.0f ? 4 : 0;
         io.scale = leaky_slope;
-        rc = launch_conv(L, packed, io, EPI_AFFINE, Do, Ho, Wo, s);
+        rc = launch_conv(L, blob, io, EPI_AFFINE, Do / J, Ho, Wo, s);
         if (rc != NND_OK) return rc;
     }
     return NND_OK;
@@ -157,6 +240,22 @@ int nnd_depth_major_to_volume(const float* x, float* y, int N, int C, int D, int
     const long HW = (long)H * W;
     hipLaunchKernelGGL(from_depth_major_kernel, dim3((unsigned)cdiv64(HW, 256), C * D, N), dim3(256), 0, (hipStream_t)stream, x, y, C, D,
                        HW);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int nnd_volume_upsample2x(const float* x, float* y, int N, int C, int D, int H, int W, void* stream) {
+    NND_REQUIRE(x && y && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (long)C * (2 * D + 2) <= 65535, "volume_upsample2x: bad argument");
+    hipLaunchKernelGGL(trilinear_up2_kernel, dim3((unsigned)cdiv64((int64_t)4 * H * W, 256), C * (2 * D + 2), N), dim3(256), 0,
+                       (hipStream_t)stream, x, y, C, D, H, W);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int nnd_volume_gate(float* vol, const float* logits, int N, int C, int D, int H, int W, void* stream) {
+    NND_REQUIRE(vol && logits && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535, "volume_gate: bad argument");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(gate_kernel, dim3((unsigned)cdiv64(HW, 256), C, N), dim3(256), 0, (hipStream_t)stream, vol, logits, C, D, HW);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

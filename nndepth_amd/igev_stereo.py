@@ -6,7 +6,9 @@ two hooks for subclasses (`_init_fnet`, `_init_cost_volume_filter`, `forward_fne
 
     backbone (`forward_fnet`)                       whatever the subclass provides (PyTorch)
     group-wise correlation volume + pyramids        HIP  csrc/corr1d.hip (GeometryAwareCostVolume)     model.py:133-141
-    3-D regulariser (Conv3d hourglass)              PyTorch-ROCm, `CostVolumeFilterNetwork` below
+    3-D regulariser (Conv3d hourglass)              HIP  csrc/conv3d.hip: every Conv3d+BN+LeakyReLU one MFMA-conv launch on
+                                                    depth-major volumes, trilinear x2 and feature gating kernels
+                                                    (`CostVolumeFilterNetwork` below; `.hip = False` keeps PyTorch ops)
     cv_squeezer Conv3d                              PyTorch-ROCm
     soft-argmin initial disparity                   HIP  nnd_softargmin_disparity                        model.py:145-146
     for iters: combined lookup -> update block -> coords += delta -> convex upsample (absolute coords, Q5)
@@ -28,7 +30,7 @@ from .raft_stereo import load_weights
 from .upsample import convex_upsample
 
 
-# ------------------------------------------------------------------ a15: 3-D regulariser (stays on PyTorch-ROCm)
+# ------------------------------------------------------------------ a15: 3-D regulariser (HIP on the GPU at inference)
 def _cbr3d(cin: int, cout: int, stride: int) -> nn.Module:
     """Conv3d(bias=False) + BatchNorm3d + LeakyReLU(0.01), parameter names conv / bn as in the reference's ConvBn3D
     (nndepth/models/igev_stereo/cost_volume.py:101-115)."""
@@ -75,8 +77,13 @@ class CostVolumeFilterNetwork(nn.Module):
         self.conv2_up_feat_guided = _Gate(2 * c, feat_channels[0])
         self.conv1_up = _cbr3d(2 * c, c, 1)
         self.final_conv = _cbr3d(c, c, 1)
+        self.hip = True  # on the GPU at inference: Conv3d / upsample / gating in HIP (False keeps the PyTorch ops)
+        self._hip, self._hip_version = None, None
 
     def forward(self, x: torch.Tensor, features: List[torch.Tensor]) -> torch.Tensor:
+        if self.hip and x.is_cuda and not self.training:
+            return self._forward_hip(x, features)
+
         def down(seq, t):
             return _run_cbr(seq[1], _run_cbr(seq[0], t))
         c1 = self.conv1_feat_guided(down(self.conv1, x), features[0])
@@ -87,6 +94,49 @@ class CostVolumeFilterNetwork(nn.Module):
         c1 = _run_cbr(self.proj_2, torch.cat((_run_cbr(self.conv2_up, c2, True), c1), dim=1))
         c1 = self.conv2_up_feat_guided(c1, features[0])
         return _run_cbr(self.final_conv, _run_cbr(self.conv1_up, c1, True))
+
+    # ---- HIP path (csrc/conv3d.hip): the whole hourglass on depth-major volumes, every Conv3d one MFMA-conv launch per sample
+    def _engines(self, device):
+        tensors = list(self.state_dict().values())
+        v = (tuple((t.data_ptr(), t._version) for t in tensors), str(device))
+        if v == self._hip_version:
+            return self._hip
+        def c3(m, stride=1, split=0):
+            bn = (m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)
+            return ops.Conv3dNorm(m.conv.weight, None, stride, bn, m.bn.eps, m.relu.negative_slope, split, device)
+        def gate(g):
+            a, bnm, _, b = g.feat_att
+            bn = (bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var)
+            return (ops.ConvNorm(a.weight, a.bias, 1, bn, bnm.eps, device), ops.ConvNorm(b.weight, b.bias, 1, None, 1e-5, device))
+        e = {}
+        for i in (1, 2, 3):
+            seq = getattr(self, f"conv{i}")
+            e[f"conv{i}"] = (c3(seq[0], 2), c3(seq[1]))
+            e[f"g{i}"] = gate(getattr(self, f"conv{i}_feat_guided"))
+        e["conv3_up"], e["conv2_up"], e["conv1_up"], e["final"] = c3(self.conv3_up), c3(self.conv2_up), c3(self.conv1_up), c3(self.final_conv)
+        e["proj_3"] = c3(self.proj_3, split=self.conv3_up.conv.out_channels)
+        e["proj_2"] = c3(self.proj_2, split=self.conv2_up.conv.out_channels)
+        e["g3u"], e["g2u"] = gate(self.conv3_up_feat_guided), gate(self.conv2_up_feat_guided)
+        self._hip, self._hip_version = e, v
+        return e
+
+    def _forward_hip(self, x: torch.Tensor, features: List[torch.Tensor]) -> torch.Tensor:
+        e = self._engines(x.device)
+        feats = [f.float() for f in features]
+
+        def gated(vol, g, feat):
+            return ops.volume_gate_(vol, g[1](g[0](feat, relu=True)))
+
+        def down(key, vol):
+            a, b = e[key]
+            return b(a(vol))
+        c1 = gated(down("conv1", ops.volume_to_depth_major(x.float())), e["g1"], feats[0])
+        c2 = gated(down("conv2", c1), e["g2"], feats[1])
+        c3 = gated(down("conv3", c2), e["g3"], feats[2])
+        c2 = gated(e["proj_3"](e["conv3_up"](ops.volume_upsample2x(c3)), c2), e["g3u"], feats[1])
+        c1 = gated(e["proj_2"](e["conv2_up"](ops.volume_upsample2x(c2)), c1), e["g2u"], feats[0])
+        out = e["final"](e["conv1_up"](ops.volume_upsample2x(c1)))
+        return ops.depth_major_to_volume(out)
 
 
 # ------------------------------------------------------------------ the model

@@ -609,3 +609,26 @@ class Conv3dNorm:
             check(lib.nnd_conv3d_forward(C.byref(self.desc), _p(self.packed), _p(x0), _p(x1), _p(y), N, D, H, W, self.leaky,
                                          _stream(d)), "conv3d_forward")
         return y
+
+
+def volume_upsample2x(x: torch.Tensor) -> torch.Tensor:
+    """Trilinear x2 (align_corners=True) of a depth-major volume (N,D+2,C,H,W) -> (N,2D+2,C,2H,2W)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Dp, Cc, H, W = x.shape
+    y = torch.empty((N, 2 * (Dp - 2) + 2, Cc, 2 * H, 2 * W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_volume_upsample2x(_p(x), _p(y), N, Cc, Dp - 2, H, W, _stream(d)), "volume_upsample2x")
+    return y
+
+
+def volume_gate_(vol: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+    """vol (N,D+2,C,H,W) *= sigmoid(logits (N,C,H,W)) in place (FeatureGuidedBlock)."""
+    d = _dev(vol, logits)
+    logits = logits.contiguous()
+    N, Dp, Cc, H, W = vol.shape
+    if not vol.is_contiguous() or tuple(logits.shape) != (N, Cc, H, W):
+        raise NndError(f"volume_gate: vol {tuple(vol.shape)} / logits {tuple(logits.shape)}")
+    with torch.cuda.device(d):
+        check(lib.nnd_volume_gate(_p(vol), _p(logits), N, Cc, Dp - 2, H, W, _stream(d)), "volume_gate")
+    return vol

@@ -758,3 +758,43 @@ def test_conv3d_norm_vs_torch(ops, Cout, Cin, split, stride, N, D, H, W):
     assert y[:, 0].abs().max() == 0 and y[:, -1].abs().max() == 0  # the zero end slices the next layer relies on
     got = ops.depth_major_to_volume(y).cpu()
     assert got.shape == ref.shape and (got - ref).abs().max() <= 3e-5
+
+
+def test_volume_upsample_and_gate_vs_torch(ops):
+    torch.manual_seed(8)
+    x = torch.randn(2, 6, 5, 7, 9)
+    ref = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="trilinear", align_corners=True)
+    got = ops.depth_major_to_volume(ops.volume_upsample2x(ops.volume_to_depth_major(x.to(DEV)))).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max() <= 2e-6
+    logits = torch.randn(2, 6, 7, 9)
+    vol = ops.volume_to_depth_major(x.to(DEV))
+    ops.volume_gate_(vol, logits.to(DEV))
+    assert vol[:, 0].abs().max() == 0 and vol[:, -1].abs().max() == 0
+    assert (ops.depth_major_to_volume(vol).cpu() - torch.sigmoid(logits).unsqueeze(2) * x).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
+def test_igev_regulariser_hip_golden(gold, name, B, H, W):
+    """a15: the Conv3d hourglass in HIP (depth-major Conv3d launches, trilinear x2, feature gating) against the reference's
+    regularised volume (tests/golden/igev_volume.npz: geo0 = level 0 of the geometry pyramid), through the drop-in
+    GeometryAwareCostVolume with the drop-in CostVolumeFilterNetwork — and against the same module's PyTorch ops."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cost_volume import GeometryAwareCostVolume
+    from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
+    g = gold("igev_volume.npz")
+    f1, f2 = t(g[name + "_f1"]).to(DEV), t(g[name + "_f2"]).to(DEV)
+    guides = [torch.from_numpy(weightgen.uniform01(f"ig{j}" + name, B * c * (H >> (j + 1)) * (W >> (j + 1))
+                                                   ).reshape(B, c, H >> (j + 1), W >> (j + 1))).to(DEV)
+              for j, c in enumerate((40, 80, 160))]
+    reg = CostVolumeFilterNetwork(8, [40, 80, 160]).eval()
+    weightgen.fill_module_(reg, "igev.cv_regularizer.")
+    reg = reg.to(DEV)
+    cv = GeometryAwareCostVolume(f1, f2, guides, reg, 4, 4, 8)
+    got = cv.geo_aware_cv[0][:, 0].cpu().numpy()
+    err = np.abs(got - g[name + "_geo0"]).max()
+    reg.hip = False
+    with torch.no_grad():
+        cv_pt = GeometryAwareCostVolume(f1, f2, guides, reg, 4, 4, 8)
+    err_pt = np.abs(cv_pt.geo_aware_cv[0][:, 0].cpu().numpy() - g[name + "_geo0"]).max()
+    print(f"\nregulariser {name}: HIP vs reference {err:.2e}, PyTorch-ROCm vs reference {err_pt:.2e} (|geo| max {np.abs(g[name + '_geo0']).max():.2f})")
+    assert err <= 2e-5
