@@ -78,6 +78,13 @@ int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid,
 int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels, void* stream);
 int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out,
                     int B, int G, int H, int W, int num_levels, int radius, void* stream);
+/* Group-interleaved copy of the levels 0..num_levels-1 of both pyramids, the layout the refinement loop gathers from:
+ * per level  il[((b*H*W + h*W + w1) * w2 + x) * 2G + v*G + g]  (v = 0 feature / 1 geometry volume), so that the
+ * 2G*(2r+1) samples of GeometryAwareCostVolume.forward (igev_stereo/cost_volume.py:54-79) for one pixel and level are
+ * one contiguous run instead of 2G rows.  Written once per pair; nnd_igev_interleaved_floats = its size.           */
+int64_t nnd_igev_interleaved_floats(int B, int G, int H, int W, int num_levels);
+int nnd_igev_interleave_pyramids(const float* feat_pyramid, const float* geo_pyramid, float* interleaved,
+                                 int B, int G, int H, int W, int num_levels, void* stream);
 
 /* ------------------------------------------------- CREStereo adaptive group correlation (AGCL)
  * Replaces AGCL.corr_iter / get_correlation / corr_att_offset and bilinear_sampler / bilinear_grid_sample
@@ -275,9 +282,12 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
 /* IGEV variant of the loop (nndepth/models/igev_stereo/model.py:148-158): lookup = nnd_igev_lookup over both
  * pyramids, and — reference quirk Q5 — the update block and the convex upsample receive the ABSOLUTE coordinate
  * coords1 = arange(W) + disp_init + sum(delta), not the disparity.  disp_init = the soft-argmin initial disparity
- * (computed by the caller: Conv3d squeezer + softmax, PyTorch).  up_out / low_out hold coordinates accordingly.  */
+ * (computed by the caller: Conv3d squeezer + softmax, PyTorch).  up_out / low_out hold coordinates accordingly.
+ * interleaved: optional (may be NULL) output of nnd_igev_interleave_pyramids for the same pyramids; when given, the
+ * per-iteration lookup gathers from it (same values, ~4x fewer HBM lines).                                        */
 int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
-                           const float* feat_pyramid, const float* geo_pyramid, int num_groups, int num_levels, int radius,
+                           const float* feat_pyramid, const float* geo_pyramid, const float* interleaved,
+                           int num_groups, int num_levels, int radius,
                            const float* net, const float* inp, const float* disp_init,
                            float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                            float* workspace, int B, int H, int W, int rate, int iters, void* stream);

@@ -60,7 +60,9 @@ SIGNATURES = {
     "nnd_mask_upsample_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_raft_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
-    "nnd_igev_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
+    "nnd_igev_interleaved_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "nnd_igev_interleave_pyramids": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_igev_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
     "nnd_cre_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                    _I, _I, _I, _I, _I, _P]),

@@ -61,6 +61,13 @@ class GeometryAwareCostVolume:
         offs, widths, _ = ops.pyramid_layout(B * self.num_groups, H, W, self.num_levels)
         return [pyr[o:o + n * w].view(n, 1, w) for o, w in zip(offs, widths)]
 
+    def interleaved(self) -> torch.Tensor:
+        """Both pyramids in the group-interleaved layout the fused refinement loop gathers from (built on first use)."""
+        if getattr(self, "_il", None) is None:
+            B, H, W = self.shape
+            self._il = ops.igev_interleave_pyramids(self._feat, self._geo, B, self.num_groups, H, W, self.num_levels)
+        return self._il
+
     @property
     def feat_corr_cv(self):
         return self._views(self._feat)

@@ -373,6 +373,186 @@ int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float*
     return NND_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// IGEV, group-interleaved pyramids.  In the reference layout (rows (b, g, h, w1) of w2 floats) the 2*G*(2r+1) samples a
+// pixel takes at one level sit in 2*G different rows, each touched for ~1.4 of its 128-B lines: ~90 lines per pixel and
+// iteration for 4 levels, 375 MB per sample at 136x240.  The interleaved copy keeps, per level,
+//     il[((b*H*W + pix) * w2 + x) * 2G + v*G + g]            v = 0 feature volume / 1 geometry volume
+// so the same samples are one contiguous run of (2r+2)*2G floats: ~22 lines per pixel and iteration.  It is written
+// once per pair (igev_interleave_kernel: a 2G x 64 LDS transpose per block) and read by every iteration of the loop.
+struct ILayout {
+    long off[MAX_LEVELS];
+    int width[MAX_LEVELS];
+};
+
+static void make_il_layout(int B, int G, int H, int W, int num_levels, ILayout* L, int64_t* total) {
+    long off = 0;
+    int w = W;
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        L->off[l] = off;
+        L->width[l] = l < num_levels ? w : 0;
+        if (l < num_levels) off += (long)B * H * W * w * 2 * G;
+        w /= 2;
+    }
+    if (total) *total = off;
+}
+
+// grid (B*H*W, ceil(w2/64)); block 256.  src rows: feat / geo [(b*G + g)*HW + pix][w2]; dst: see above.
+__global__ void __launch_bounds__(256) igev_interleave_kernel(const float* __restrict__ feat, const float* __restrict__ geo,
+                                                              float* __restrict__ dst, int G, long HW, int w2) {
+    __shared__ float sm[32 * 68];
+    const int VG = 2 * G;  // <= 32
+    const long bp = blockIdx.x, b = bp / HW, pix = bp - b * HW;
+    const int x0 = blockIdx.y * 64, nx = min(64, w2 - x0);
+    for (int i = threadIdx.x; i < VG * 64; i += 256) {
+        const int vg = i >> 6, x = i & 63;
+        if (x < nx) {
+            const int v = vg / G, g = vg - v * G;
+            sm[vg * 68 + x] = (v ? geo : feat)[((b * G + g) * HW + pix) * w2 + x0 + x];
+        }
+    }
+    __syncthreads();
+    float* o = dst + (bp * w2 + x0) * VG;
+    for (int i = threadIdx.x; i < VG * nx; i += 256) o[i] = sm[(i % VG) * 68 + i / VG];
+}
+
+// lookup + convc1 over the interleaved pyramids (G = 8, radius 4: VG = 16 runs of NTAP = 9 taps, 144 planes per level).
+// One workgroup = two 4x8 pixel sub-tiles (64 pixels), 8 waves = 8 x 32 output channels; every weight fragment read
+// from L2 feeds two MFMAs.  K is walked level by level: while the MFMAs of level l run out of one LDS buffer, the gathers
+// of level l+1 are in flight (thread = (pixel, v*G+g): its 9 taps are consecutive 2G-float steps of one contiguous run;
+// the 16 lanes of a pixel read 64 contiguous bytes), then blended into the other buffer.  The weights are the packed
+// convc1 layer (conv_mfma fragment order; one float4 per lane and group of 4 k-pairs, prefetched one group ahead).
+// Same arithmetic and K order as lookup_convc1_kernel<true>: bit-identical output.
+constexpr int IL_VG = 16, IL_NTAP = 9, IL_LC = IL_VG * IL_NTAP, IL_S = 68;  // IL_S: LDS row stride (64 pixels + 4: conflict-free)
+__global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_kernel(const float* __restrict__ il, const float* __restrict__ coords,
+                                                                      const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                                      float* __restrict__ out, long obs, ILayout IL, Lay lay,
+                                                                      int H, int W, int num_levels, int ntiles, int tiles_x,
+                                                                      int cb_stride) {
+    extern __shared__ float xs[];  // [2][IL_LC][IL_S]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const long HW = (long)H * W;
+    // gather role: items tid and tid + 512 of the 64 pixels x 16 runs
+    const int vg = tid & 15;
+    long pixo[2];   // float offset of the pixel's run at level 0 divided by w2*VG, i.e. the row index b*HW + pix
+    float cval[2];
+    bool pin[2];
+    int pcol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px64 = (tid >> 4) + 32 * i, t = blockIdx.x * 2 + (px64 >> 5), px = px64 & 31;
+        const int py = (t / tiles_x) * 4 + (px >> 3), pxx = (t % tiles_x) * 8 + (px & 7);
+        pin[i] = t < ntiles && py < H && pxx < W;
+        const long pix = pin[i] ? (long)py * W + pxx : 0;
+        pixo[i] = (long)b * HW + pix;
+        cval[i] = pin[i] ? coords[(long)b * lay.plane + pix_off(lay, py, pxx)] : 0.f;
+        pcol[i] = px64;
+    }
+    float v0[2][IL_NTAP], v1[2][IL_NTAP];
+    auto fetch = [&](int lvl) {
+        const int w2 = IL.width[lvl];
+        const float wm1 = (float)(w2 - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* base = il + IL.off[lvl] + pixo[i] * w2 * IL_VG + vg;
+#pragma unroll
+            for (int k = 0; k < IL_NTAP; ++k) {
+                float x = cval[i] / (float)(1 << lvl) + (float)(k - IL_NTAP / 2);
+                x = x / wm1;
+                x = fminf(fmaxf(x, 0.f), 1.f);
+                x = x * wm1;
+                v0[i][k] = base[(int)floorf(x) * IL_VG];
+                v1[i][k] = base[(int)ceilf(x) * IL_VG];
+            }
+        }
+    };
+    auto put = [&](int lvl, float* buf) {
+        const float wm1 = (float)(IL.width[lvl] - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < IL_NTAP; ++k) {
+                float x = cval[i] / (float)(1 << lvl) + (float)(k - IL_NTAP / 2);
+                x = x / wm1;
+                x = fminf(fmaxf(x, 0.f), 1.f);
+                x = x * wm1;
+                const float cf = ceilf(x) - x;
+                buf[(vg * IL_NTAP + k) * IL_S + pcol[i]] = pin[i] ? cf * v0[i][k] + (1.0f - cf) * v1[i][k] : 0.f;
+            }
+    };
+    fetch(0);
+    put(0, xs);
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = 0.f, acc1[i] = 0.f;
+    const float4* wq = reinterpret_cast<const float4*>(wpk) + (size_t)wave * cb_stride + lane;  // + qq*64: group qq of 4 k-pairs
+    constexpr int NQ = IL_LC / 8;                                                              // groups per level
+    float4 av = wq[0];
+    for (int lvl = 0; lvl < num_levels; ++lvl) {
+        const bool more = lvl + 1 < num_levels;
+        if (more) fetch(lvl + 1);
+        const float* xb = xs + (lvl & 1) * (IL_LC * IL_S) + h2 * IL_S + l31;
+#pragma unroll 2
+        for (int q = 0; q < NQ; ++q) {
+            const int qq = lvl * NQ + q;
+            const float4 an = wq[(size_t)min(qq + 1, num_levels * NQ - 1) * 64];
+            const float as[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* xr = xb + (q * 4 + j) * 2 * IL_S;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], xr[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], xr[32], acc1, 0, 0, 0);
+            }
+            av = an;
+        }
+        if (more) put(lvl + 1, xs + ((lvl + 1) & 1) * (IL_LC * IL_S));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = blockIdx.x * 2 + p;
+        const int y = (t / tiles_x) * 4 + (l31 >> 3), x = (t % tiles_x) * 8 + (l31 & 7);
+        if (t >= ntiles || y >= H || x >= W) continue;
+        float* o = out + (long)b * obs + pix_off(lay, y, x);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+            o[(long)co * lay.plane] = fmaxf((p ? acc1[reg] : acc0[reg]) + bias[co], 0.f);
+        }
+    }
+}
+
+// false: shape not covered by the kernel above (the caller falls back to lookup_convc1_launch on the reference layout)
+bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius) {
+    return 2 * G == IL_VG && 2 * radius + 1 == IL_NTAP && num_levels >= 1 && num_levels < MAX_LEVELS;
+}
+
+int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, const ConvLayer& L, const float* blob, float* c1,
+                                 int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream) {
+    NND_REQUIRE(igev_lookup_convc1_il_supported(G, num_levels, radius), "igev_lookup_convc1: groups %d / radius %d not built", G, radius);
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 && L.Cin == num_levels * IL_LC,
+                "igev_lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
+    ILayout IL;
+    make_il_layout(B, G, H, W, num_levels, &IL, nullptr);
+    NND_REQUIRE(IL.width[num_levels - 1] >= 2, "igev_lookup_convc1: level %d has width %d < 2", num_levels - 1, IL.width[num_levels - 1]);
+    const size_t lds = 2 * IL_LC * IL_S * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(igev_lookup_convc1_il_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
+    const int cb_stride = L.nchunks * (L.CI_T / 8) * 64;
+    hipLaunchKernelGGL(igev_lookup_convc1_il_kernel, dim3(cdiv(ntiles, 2), 1, B), dim3(512), lds, stream, il, coords, blob + L.w_off,
+                       blob + L.b_off, c1, (long)c1_bs, IL, make_lay(H, W, true), H, W, num_levels, ntiles, tiles_x, cb_stride);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
 int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,
                            hipStream_t stream, bool tiled) {
     const Lay lay = make_lay(H, W, tiled);
@@ -464,6 +644,34 @@ int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels,
     return NND_OK;
 }
 
+
+int64_t nnd_igev_interleaved_floats(int B, int G, int H, int W, int num_levels) {
+    if (B <= 0 || G <= 0 || H <= 0 || W <= 0 || num_levels < 1 || num_levels >= MAX_LEVELS) return 0;
+    ILayout IL;
+    int64_t total;
+    make_il_layout(B, G, H, W, num_levels, &IL, &total);
+    return total;
+}
+
+int nnd_igev_interleave_pyramids(const float* feat_pyramid, const float* geo_pyramid, float* interleaved, int B, int G, int H,
+                                 int W, int num_levels, void* stream) {
+    NND_REQUIRE(feat_pyramid && geo_pyramid && interleaved, "igev_interleave_pyramids: null pointer");
+    NND_REQUIRE(B > 0 && G > 0 && 2 * G <= 32 && H > 0 && W > 0 && num_levels >= 1 && num_levels < MAX_LEVELS,
+                "igev_interleave_pyramids: bad shape");
+    PyrLayout L;
+    make_layout(B * G, H, W, num_levels + 1, &L, nullptr);
+    ILayout IL;
+    make_il_layout(B, G, H, W, num_levels, &IL, nullptr);
+    const long HW = (long)H * W;
+    NND_REQUIRE((long)B * HW < (1L << 31), "igev_interleave_pyramids: too many rows");
+    for (int l = 0; l < num_levels; ++l) {
+        if (L.width[l] == 0) break;
+        hipLaunchKernelGGL(igev_interleave_kernel, dim3((unsigned)(B * HW), cdiv(L.width[l], 64)), dim3(256), 0, (hipStream_t)stream,
+                           feat_pyramid + L.off[l], geo_pyramid + L.off[l], interleaved + IL.off[l], G, HW, L.width[l]);
+        NND_LAUNCH_CHECK();
+    }
+    return NND_OK;
+}
 }  // extern "C"
 
 namespace nnd {

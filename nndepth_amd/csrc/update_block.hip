@@ -624,7 +624,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
                           int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
                           int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W,
                           int rate, int iters, void* stream, const float* geo_pyramid = nullptr, int groups = 1,
-                          const CreArgs* cre = nullptr) {
+                          const CreArgs* cre = nullptr, const float* interleaved = nullptr) {
     Plan p;
     int rc = make_plan(desc, &p);
     if (rc != NND_OK) return rc;
@@ -698,7 +698,10 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, st->a));
         NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
         NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
-        if (fused_lk) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
+        if (fused_lk && interleaved && igev_lookup_convc1_il_supported(groups, num_levels, radius)) {  // IGEV over the group-interleaved copy of both pyramids
+            NND_TRY(igev_lookup_convc1_il_launch(interleaved, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W, num_levels,
+                                                 radius, s));
+        } else if (fused_lk) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
             NND_TRY(lookup_convc1_launch(pyramid, geo_pyramid, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W,
                                          num_levels, radius, s));
         } else {
@@ -785,12 +788,13 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
 }
 
 int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* feat_pyramid,
-                           const float* geo_pyramid, int num_groups, int num_levels, int radius, const float* net, const float* inp,
+                           const float* geo_pyramid, const float* interleaved, int num_groups, int num_levels, int radius,
+                           const float* net, const float* inp,
                            const float* disp_init, float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                            float* workspace, int B, int H, int W, int rate, int iters, void* stream) {
     NND_REQUIRE(geo_pyramid && num_groups > 0, "igev_stereo_refine: geometry pyramid / groups missing");
     return enqueue_refine(desc, packed, feat_pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
-                          net_out, workspace, B, H, W, rate, iters, stream, geo_pyramid, num_groups);
+                          net_out, workspace, B, H, W, rate, iters, stream, geo_pyramid, num_groups, nullptr, interleaved);
 }
 
 int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* fmap1, const float* fmap2,

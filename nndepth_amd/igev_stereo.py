@@ -201,7 +201,8 @@ class IGEVStereoBase(nn.Module):
         if self.fused_loop and isinstance(corr, GeometryAwareCostVolume):
             eng = self.update_block.sync_engine(frame1.device)
             up, _, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,
-                                       net.float(), inp.float(), fnet_ds, self.iters, disp_init=init, keep_all=True)
+                                       net.float(), inp.float(), fnet_ds, self.iters, disp_init=init, keep_all=True,
+                                       interleaved=corr.interleaved())
             return [{"up_disp": up[i]} for i in range(self.iters)]
         coords1 = self.initialize_coords(fmap1) + init
         outs = []

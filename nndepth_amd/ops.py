@@ -221,8 +221,9 @@ class UpdateBlockEngine:
         return up, low, net_out
 
     def refine_igev(self, feat_pyr, geo_pyr, num_groups: int, num_levels: int, radius: int, net, inp, rate: int,
-                    iters: int, disp_init=None, keep_all: bool = True):
-        """IGEV loop (absolute coordinates, combined lookup) -> (up, low, net) like refine()."""
+                    iters: int, disp_init=None, keep_all: bool = True, interleaved=None):
+        """IGEV loop (absolute coordinates, combined lookup) -> (up, low, net) like refine().
+        interleaved: optional igev_interleave_pyramids(feat_pyr, geo_pyr, ...) — the loop then gathers from it."""
         if self.packed is None:
             raise NndError("UpdateBlockEngine: parameters not loaded")
         d = _dev(feat_pyr, geo_pyr, net, inp, self.packed)
@@ -237,7 +238,7 @@ class UpdateBlockEngine:
         if disp_init is not None:
             disp_init = disp_init.contiguous()
         with torch.cuda.device(d):
-            check(lib.nnd_igev_stereo_refine(C.byref(self.desc), _p(self.packed), _p(feat_pyr), _p(geo_pyr), num_groups,
+            check(lib.nnd_igev_stereo_refine(C.byref(self.desc), _p(self.packed), _p(feat_pyr), _p(geo_pyr), _p(interleaved), num_groups,
                                              num_levels, radius, _p(net), _p(inp), _p(disp_init), _p(up), stride, _p(low),
                                              _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "igev_stereo_refine")
         return up, low, net_out
@@ -327,6 +328,17 @@ def igev_lookup(feat_pyr: torch.Tensor, geo_pyr: torch.Tensor, coords: torch.Ten
     with torch.cuda.device(d):
         check(lib.nnd_igev_lookup(_p(feat_pyr), _p(geo_pyr), _p(coords), _p(out), B, num_groups, H, W, num_levels,
                                   radius, _stream(d)), "igev_lookup")
+    return out
+
+
+def igev_interleave_pyramids(feat_pyr: torch.Tensor, geo_pyr: torch.Tensor, B: int, num_groups: int, H: int, W: int,
+                             num_levels: int) -> torch.Tensor:
+    """Group-interleaved copy of both pyramids (levels 0..num_levels-1) for the refinement loop's gathers."""
+    d = _dev(feat_pyr, geo_pyr)
+    out = torch.empty(lib.nnd_igev_interleaved_floats(B, num_groups, H, W, num_levels), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_igev_interleave_pyramids(_p(feat_pyr), _p(geo_pyr), _p(out), B, num_groups, H, W, num_levels,
+                                               _stream(d)), "igev_interleave_pyramids")
     return out
 
 

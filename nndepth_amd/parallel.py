@@ -54,4 +54,7 @@ def max_over_ranks(seconds: float, device) -> float:
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -44,7 +44,11 @@ for B in (1, 8):
     lvl0 = feat[:B * G * H * W * W].clone()
     t_pyr = timeit(lambda: ops.pyramid_from_level0(lvl0, B * G, H, W, 4))
     geo = ops.pyramid_from_level0(lvl0, B * G, H, W, 4)
-    t_loop = timeit(lambda: eng.refine_igev(feat, geo, G, 4, 4, net, inp, 4, 32, disp_init=init, keep_all=True), reps=2)
-    print(f"config 3 hot path, batch {B}: volume build {t_build * 1e3:.2f} ms, geo pyramid {t_pyr * 1e3:.2f} ms, 32-iteration loop {t_loop * 1e3:.1f} ms "
-          f"({t_loop / 32 / B * 1e6:.0f} us per iteration and sample)")
-    del feat, geo, lvl0
+    t_il = timeit(lambda: ops.igev_interleave_pyramids(feat, geo, B, G, H, W, 4))
+    il = ops.igev_interleave_pyramids(feat, geo, B, G, H, W, 4)
+    t_loop0 = timeit(lambda: eng.refine_igev(feat, geo, G, 4, 4, net, inp, 4, 32, disp_init=init, keep_all=True), reps=2)
+    t_loop = timeit(lambda: eng.refine_igev(feat, geo, G, 4, 4, net, inp, 4, 32, disp_init=init, keep_all=True, interleaved=il), reps=2)
+    print(f"config 3 hot path, batch {B}: volume build {t_build * 1e3:.2f} ms, geo pyramid {t_pyr * 1e3:.2f} ms, interleave {t_il * 1e3:.2f} ms, "
+          f"32-iteration loop {t_loop * 1e3:.1f} ms ({t_loop / 32 / B * 1e6:.0f} us per iteration and sample; "
+          f"{t_loop0 / 32 / B * 1e6:.0f} us gathering from the reference-layout pyramids)")
+    del feat, geo, lvl0, il

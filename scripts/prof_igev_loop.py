@@ -14,6 +14,8 @@ net, inp = torch.tanh(torch.randn(B, 64, H, W, device=dev)), torch.relu(torch.ra
 init = -20 * torch.rand(B, 1, H, W, device=dev)
 feat = ops.group_corr_build(fm1, fm2, G, G, 4)
 geo = ops.pyramid_from_level0(feat[:B * G * H * W * W].clone(), B * G, H, W, 4)
+il = ops.igev_interleave_pyramids(feat, geo, B, G, H, W, 4)
 for _ in range(2):
     eng.refine_igev(feat, geo, G, 4, 4, net, inp, 4, 4, disp_init=init, keep_all=True)
+    eng.refine_igev(feat, geo, G, 4, 4, net, inp, 4, 4, disp_init=init, keep_all=True, interleaved=il)
 torch.cuda.synchronize()

@@ -377,9 +377,25 @@ def test_igev_refine_loop_vs_oracle(R):
         ub.load_state_dict({k[len("update_block."):]: v for k, v in sd.items()})
         eng = ub.to(DEV).sync_engine(DEV)
         up, low, _ = eng.refine_igev(cv._feat, cv._geo, G, 4, 4, net.to(DEV), inp.to(DEV), 4, iters, disp_init=init.to(DEV))
+        # the loop gathering from the group-interleaved copy of the pyramids: same arithmetic, same accumulation order
+        il = cv.interleaved()
+        up_il, low_il, _ = eng.refine_igev(cv._feat, cv._geo, G, 4, 4, net.to(DEV), inp.to(DEV), 4, iters, disp_init=init.to(DEV),
+                                           interleaved=il)
     for i in range(iters):
         err = (up[i].cpu() - exp[i]).abs().max().item()
         assert err <= 2e-4 * max(1.0, exp[i].abs().max().item() / 40), f"iter {i}: {err}"
+    assert torch.equal(up_il, up) and torch.equal(low_il, low)
+    # layout of the interleaved copy: il[((b*HW + pix)*w2 + x)*2G + v*G + g] per level
+    offs, widths, _ = ops.pyramid_layout(B * G, H, W, 4)
+    o_il = 0
+    for lvl in range(4):
+        w2, n = widths[lvl], B * G * H * W
+        f = cv._feat[offs[lvl]:offs[lvl] + n * w2].view(B, G, H * W, w2)
+        g_ = cv._geo[offs[lvl]:offs[lvl] + n * w2].view(B, G, H * W, w2)
+        want = torch.stack([f, g_], 1).permute(0, 3, 4, 1, 2).reshape(-1)  # (B, HW, w2, 2, G)
+        assert torch.equal(il[o_il:o_il + want.numel()], want), f"level {lvl}"
+        o_il += want.numel()
+    assert o_il == il.numel()
 
 
 # ------------------------------------------------------------ CREStereo AGCL + sampler (a17-a19)
