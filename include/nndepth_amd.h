@@ -110,6 +110,12 @@ int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* fl
  *   nndepth/models/igev_stereo/model.py:92-95,145-146
  * logits (B,D,H,W) = the squeezed geometry volume -> out (B,1,H,W) = -sum_d d * softmax_d(logits).              */
 int nnd_softargmin_disparity(const float* logits, float* out, int B, int D, int H, int W, void* stream);
+/* cv_squeezer + regress_disparity in one pass (nndepth/models/igev_stereo/model.py:63,144-146): geo_level0 = level 0 of
+ * the geometry pyramid, rows (b,g,h,w1) of D floats (GeometryAwareCostVolume.geo_aware_cv[0]); weight = the
+ * Conv3d(G,1,3,1,1) kernel (1,G,3,3,3) over (candidate, h, w1), bias (1) or NULL — both HOST pointers (they travel as
+ * kernel arguments); out (B,1,H,W) = -sum_d d * softmax_d(conv3d(geo)).  G <= 8, D <= 512, else NND_ERR_UNSUPPORTED. */
+int nnd_igev_init_disparity(const float* geo_level0, const float* weight_host, const float* bias_host, float* out,
+                            int B, int G, int H, int W, int D, void* stream);
 
 /* ----------------------------------------------------------------------- convex upsample
  * Replaces RAFTStereo.convex_upsample  nndepth/models/raft_stereo/model.py:93-105

@@ -45,6 +45,7 @@ SIGNATURES = {
     "nnd_pyramid_from_level0": (_I, [_P, _I, _I, _I, _I, _P]),
     "nnd_igev_lookup": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_softargmin_disparity": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "nnd_igev_init_disparity": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_convex_upsample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_bilinear_sample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_agcl_corr_iter": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -710,11 +710,191 @@ __global__ void __launch_bounds__(256) softargmin_kernel(const float* __restrict
     out[idx] = -acc;
 }
 
+// IGEV cv_squeezer + initial disparity in one pass over the regularised volume (igev_stereo/model.py:144-146):
+//   logits[b,d,h,w] = bias + sum_{g,kd,kh,kw} Wt[g][kd][kh][kw] * geo[b,g,h+kh-1,w+kw-1,d+kd-1]   (Conv3d(G,1,3,1,1), zero pad)
+//   out[b,0,h,w]    = -sum_d d * softmax_d(logits)
+// geo = level 0 of the geometry pyramid, rows (b,g,h,w1) of D = W2 floats, read in place (the reference permutes it to
+// (B,G,W2,H,W1) for the Conv3d; here the candidate axis stays the contiguous one).  One workgroup = SQ_PX pixels of one
+// image row; thread = candidate d (DPT per thread).  Per group g the 3 x (SQ_PX+2) neighbour rows go through LDS
+// (zero-padded by one candidate either side), every LDS value feeds up to 9 FMAs from registers; the logits never
+// reach HBM.  Weights sit in the kernel arguments (scalar registers).
+constexpr int SQ_PX = 8, SQ_MAXG = 8;
+struct SqueezeArgs {
+    float w[SQ_MAXG * 27];  // [g][kd][kh][kw]
+    float bias;
+};
+
+template <int DPT>
+__global__ void __launch_bounds__(256) igev_squeeze_softargmin_kernel(const float* __restrict__ geo, float* __restrict__ out,
+                                                                      SqueezeArgs a, int G, int H, int W, int D) {
+    extern __shared__ float sm[];  // [3][SQ_PX + 2][D + 2]
+    __shared__ float red[4][SQ_PX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware mapping: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each); XCD x gets the band of
+    // image rows [x*band, (x+1)*band), so the three rows a workgroup shares with its vertical neighbours stay in one L2
+    const int nx = (W + SQ_PX - 1) / SQ_PX, band = (H + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int h = xcd * band + slot / nx, w0 = (slot % nx) * SQ_PX, b = blockIdx.z;
+    if (h >= H) return;
+    const int DS = D + 2;
+    float acc[DPT][SQ_PX];
+#pragma unroll
+    for (int j = 0; j < DPT; ++j)
+#pragma unroll
+        for (int p = 0; p < SQ_PX; ++p) acc[j][p] = 0.f;
+    // rows of group g: 3 x (SQ_PX+2) rows of D floats.  D % 4 == 0: 16-byte loads, the rows of group g+1 are fetched into
+    // registers while group g is multiplied (latency hidden behind the FMAs); else scalar loads straight into LDS.
+    constexpr int NROW = 3 * (SQ_PX + 2), NL = (NROW * (DPT * 64) + 255) / 256;
+    const bool vec = (D & 3) == 0;
+    const int nq = D >> 2;
+    float4 stage[NL];
+    auto row_src = [&](int g, int r, bool& ok) {
+        const int kh = r / (SQ_PX + 2), c = r - kh * (SQ_PX + 2);
+        const int hh = h + kh - 1, ww = w0 + c - 1;
+        ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+        return geo + ((((long)b * G + g) * H + (ok ? hh : 0)) * W + (ok ? ww : 0)) * D;
+    };
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + 256 * k;
+            const bool in = i < NROW * nq;
+            const int r = in ? i / nq : 0, q = in ? i - r * nq : 0;
+            bool ok;
+            const float* src = row_src(g, r, ok);
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+            stage[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NROW * nq) {
+                const int r = i / nq, q = i - r * nq;
+                float* dst = sm + r * DS + 1 + 4 * q;
+                dst[0] = stage[k].x; dst[1] = stage[k].y; dst[2] = stage[k].z; dst[3] = stage[k].w;
+            }
+        }
+    };
+    for (int r = tid; r < NROW; r += 256) sm[r * DS] = 0.f, sm[r * DS + D + 1] = 0.f;  // candidate -1 and D: zero padding
+    if (vec) fetch(0);
+    for (int g = 0; g < G; ++g) {
+        __syncthreads();
+        if (vec) {
+            commit();
+        } else {
+            for (int r = 0; r < NROW; ++r) {
+                bool ok;
+                const float* src = row_src(g, r, ok);
+                for (int d = tid; d < D; d += 256) sm[r * DS + 1 + d] = ok ? src[d] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (vec && g + 1 < G) fetch(g + 1);
+        const float* wg = a.w + g * 27;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            const int d = tid + 256 * j;
+            if (d < D) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int c = 0; c < SQ_PX + 2; ++c) {
+                        const float* row = sm + (kh * (SQ_PX + 2) + c) * DS + d;
+                        const float r0 = row[0], r1 = row[1], r2 = row[2];
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int p = c - kw;
+                            if (p >= 0 && p < SQ_PX)
+                                acc[j][p] += wg[0 * 9 + kh * 3 + kw] * r0 + wg[1 * 9 + kh * 3 + kw] * r1 + wg[2 * 9 + kh * 3 + kw] * r2;
+                        }
+                    }
+            }
+        }
+    }
+    // soft-argmin over the candidates: block reductions (max, sum of exp, sum of d*exp) for the SQ_PX pixels at once
+    auto block_reduce = [&](float (&v)[SQ_PX], bool is_max) {
+#pragma unroll
+        for (int p = 0; p < SQ_PX; ++p) {
+            float x = v[p];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float y = __shfl_xor(x, o);
+                x = is_max ? fmaxf(x, y) : x + y;
+            }
+            v[p] = x;
+        }
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int p = 0; p < SQ_PX; ++p) red[wave][p] = v[p];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < SQ_PX; ++p)
+            v[p] = is_max ? fmaxf(fmaxf(red[0][p], red[1][p]), fmaxf(red[2][p], red[3][p])) : (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+    };
+    float mx[SQ_PX], se[SQ_PX], sd[SQ_PX];
+#pragma unroll
+    for (int p = 0; p < SQ_PX; ++p) {
+        mx[p] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j)
+            if (tid + 256 * j < D) mx[p] = fmaxf(mx[p], acc[j][p] + a.bias);
+    }
+    block_reduce(mx, true);
+#pragma unroll
+    for (int p = 0; p < SQ_PX; ++p) {
+        se[p] = 0.f;
+        sd[p] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            const int d = tid + 256 * j;
+            if (d < D) {
+                const float e = expf(acc[j][p] + a.bias - mx[p]);
+                se[p] += e;
+                sd[p] += (float)d * e;
+            }
+        }
+    }
+    block_reduce(se, false);
+    block_reduce(sd, false);
+    if (tid < SQ_PX && w0 + tid < W) {
+        float r = 0.f;
+#pragma unroll
+        for (int p = 0; p < SQ_PX; ++p)
+            if (p == tid) r = -(sd[p] / se[p]);
+        out[((long)b * H + h) * W + w0 + tid] = r;
+    }
+}
+
 extern "C" {
 int nnd_softargmin_disparity(const float* logits, float* out, int B, int D, int H, int W, void* stream) {
     NND_REQUIRE(logits && out && B > 0 && D > 0 && H > 0 && W > 0, "softargmin_disparity: bad argument");
     const long HW = (long)H * W, total = (long)B * HW;
     hipLaunchKernelGGL(softargmin_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, logits, out, D, HW, total);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int nnd_igev_init_disparity(const float* geo_level0, const float* weight, const float* bias, float* out, int B, int G, int H,
+                            int W, int D, void* stream) {
+    NND_REQUIRE(geo_level0 && weight && out, "igev_init_disparity: null pointer");
+    NND_REQUIRE(B > 0 && G > 0 && H > 0 && W > 0 && D > 0, "igev_init_disparity: bad shape");
+    if (G > SQ_MAXG || D > 512 || B > 65535) {
+        set_error("igev_init_disparity: groups %d (max %d) / candidates %d (max 512) not built", G, SQ_MAXG, D);
+        return NND_ERR_UNSUPPORTED;
+    }
+    SqueezeArgs a;  // weight / bias are HOST pointers: the 27*G weights and the bias travel as kernel arguments
+    for (int i = 0; i < G * 27; ++i) a.w[i] = weight[i];
+    for (int i = G * 27; i < SQ_MAXG * 27; ++i) a.w[i] = 0.f;
+    a.bias = bias ? bias[0] : 0.f;
+    const size_t lds = (size_t)3 * (SQ_PX + 2) * (D + 2) * sizeof(float);
+    dim3 grid(cdiv(W, SQ_PX) * 8 * cdiv(H, 8), 1, B), block(256);  // 8 bands of ceil(H/8) rows, see the kernel
+    if (D <= 256)
+        hipLaunchKernelGGL(igev_squeeze_softargmin_kernel<1>, grid, block, lds, (hipStream_t)stream, geo_level0, out, a, G, H, W, D);
+    else
+        hipLaunchKernelGGL(igev_squeeze_softargmin_kernel<2>, grid, block, lds, (hipStream_t)stream, geo_level0, out, a, G, H, W, D);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

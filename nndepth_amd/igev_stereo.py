@@ -9,8 +9,7 @@ two hooks for subclasses (`_init_fnet`, `_init_cost_volume_filter`, `forward_fne
     3-D regulariser (Conv3d hourglass)              HIP  csrc/conv3d.hip: every Conv3d+BN+LeakyReLU one MFMA-conv launch on
                                                     depth-major volumes, trilinear x2 and feature gating kernels
                                                     (`CostVolumeFilterNetwork` below; `.hip = False` keeps PyTorch ops)
-    cv_squeezer Conv3d                              PyTorch-ROCm
-    soft-argmin initial disparity                   HIP  nnd_softargmin_disparity                        model.py:145-146
+    cv_squeezer Conv3d + soft-argmin init           HIP  nnd_igev_init_disparity (one pass over the volume) model.py:144-146
     for iters: combined lookup -> update block -> coords += delta -> convex upsample (absolute coords, Q5)
                                                     HIP, ONE C-ABI call: nnd_igev_stereo_refine          model.py:152-158
 
@@ -160,6 +159,14 @@ class IGEVStereoBase(nn.Module):
         self.weights, self.strict_load = weights, strict_load
         self.fused_loop = fused_loop
 
+    def _squeezer_host(self):
+        """Host copy of the cv_squeezer parameters (kernel arguments of nnd_igev_init_disparity), refreshed when they change."""
+        w, b = self.cv_squeezer.weight, self.cv_squeezer.bias
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+        if getattr(self, "_sq_cache", (None,))[0] != key:
+            self._sq_cache = (key, w.detach().float().cpu().contiguous(), None if b is None else b.detach().float().cpu().contiguous())
+        return self._sq_cache[1], self._sq_cache[2]
+
     def _init_fnet(self):
         raise NotImplementedError("Must be implemented in child class")
 
@@ -192,12 +199,13 @@ class IGEVStereoBase(nn.Module):
                             self.cv_groups)
         B, _, H1, W1 = fmap1.shape
         W2 = fmap2.shape[-1]
-        geo = corr.geo_aware_cv[0].reshape(B, self.cv_groups, H1, W1, W2).permute(0, 1, 4, 2, 3)
-        logits = self.cv_squeezer(geo).squeeze(1)  # (B, W2, H1, W1)
-        if logits.is_cuda:
-            init = ops.softargmin_disparity(logits.float())
+        geo0 = corr.geo_aware_cv[0]
+        if geo0.is_cuda and ops.igev_init_disparity_supported(self.cv_groups, W2):
+            # cv_squeezer + softmax + regress_disparity as one kernel over the volume where it lies
+            init = ops.igev_init_disparity(geo0, *self._squeezer_host(), B, self.cv_groups, H1, W1, W2)
         else:
-            init = self.regress_disparity(F.softmax(logits, dim=1), W1)
+            logits = self.cv_squeezer(geo0.reshape(B, self.cv_groups, H1, W1, W2).permute(0, 1, 4, 2, 3)).squeeze(1)
+            init = ops.softargmin_disparity(logits.float()) if logits.is_cuda else self.regress_disparity(F.softmax(logits, dim=1), W1)
         if self.fused_loop and isinstance(corr, GeometryAwareCostVolume):
             eng = self.update_block.sync_engine(frame1.device)
             up, _, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,

@@ -517,6 +517,26 @@ def softargmin_disparity(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def igev_init_disparity_supported(num_groups: int, D: int) -> bool:
+    return num_groups <= 8 and D <= 512
+
+
+def igev_init_disparity(geo_level0: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], B: int, G: int, H: int,
+                        W: int, D: int) -> torch.Tensor:
+    """cv_squeezer Conv3d(G,1,3,1,1) + soft-argmin in one kernel (igev_stereo/model.py:144-146): geo_level0 = rows
+    (b,g,h,w1) of D candidates on the device, weight (1,G,3,3,3) / bias (1) = the squeezer's parameters -> (B,1,H,W)."""
+    d = _dev(geo_level0)
+    assert geo_level0.numel() == B * G * H * W * D and tuple(weight.shape) == (1, G, 3, 3, 3)
+    # 27*G floats passed by value to the kernel: hand in host tensors (a device tensor costs a synchronising copy here)
+    wh = weight.detach().to("cpu", torch.float32).contiguous()
+    bh = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_igev_init_disparity(_p(geo_level0.contiguous()), _p(wh), _p(bh), _p(out), B, G, H, W, D, _stream(d)),
+              "igev_init_disparity")
+    return out
+
+
 LOFTR_KEYS = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight", "mlp.2.weight",
               "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
 

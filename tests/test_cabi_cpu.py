@@ -182,6 +182,9 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.nnd_agcl_corr_iter(None, None, None, None, None, 1, 32, 8, 8, 0, None) < 0
     assert lib.nnd_agcl_corr_offset(None, None, None, None, None, 1, 32, 8, 8, 0, None) < 0
     assert lib.nnd_softargmin_disparity(None, None, 1, 8, 4, 4, None) < 0
+    assert lib.nnd_igev_init_disparity(None, None, None, None, 1, 8, 4, 4, 4, None) < 0
+    assert lib.nnd_igev_interleave_pyramids(None, None, None, 1, 8, 4, 4, 4, None) < 0
+    assert lib.nnd_igev_interleaved_floats(1, 8, 4, 8, 2) == 4 * 8 * (8 + 4) * 16
     d = ConvDesc(16, 16, 3, 3, 3)
     assert lib.nnd_conv_packed_floats(C.byref(d)) < 0 and b"stride" in lib.nnd_last_error()
     assert lib.nnd_conv_forward(C.byref(ConvDesc(16, 16, 3, 3, 1)), None, None, None, None, 1, 8, 8, 0, 0, None) < 0

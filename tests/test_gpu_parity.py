@@ -617,6 +617,20 @@ def test_igev_softargmin_vs_oracle(ops, R):
         assert (got - exp).abs().max() <= 2e-5 * D, (B, D, H, W)
 
 
+def test_igev_squeezer_init_vs_oracle(ops, R):
+    """cv_squeezer Conv3d(G,1,3,1,1) + soft-argmin fused (nnd_igev_init_disparity) vs the PyTorch CPU ops of the reference
+    (igev_stereo/model.py:144-146), incl. ragged widths, one candidate per thread and two (D > 256), G < 8."""
+    torch.manual_seed(14)
+    for (B, G, H, W, D, amp) in ((2, 8, 9, 21, 21, 1.0), (1, 8, 5, 13, 300, 0.5), (1, 3, 4, 8, 7, 2.0), (1, 8, 3, 17, 240, 1.0)):
+        geo = torch.randn(B, G, H, W, D) * amp
+        conv = torch.nn.Conv3d(G, 1, 3, 1, 1)
+        with torch.no_grad():
+            exp = R.igev_init_disparity(conv(geo.permute(0, 1, 4, 2, 3)).squeeze(1))
+            got = ops.igev_init_disparity(geo.to(DEV), conv.weight, conv.bias, B, G, H, W, D).cpu()
+        assert got.shape == exp.shape
+        assert (got - exp).abs().max() <= 2e-5 * D, (B, G, H, W, D, float((got - exp).abs().max()))
+
+
 def test_igev_forward_golden(gold):
     """Whole IGEVStereoBase.forward (HIP volume + pyramids, PyTorch regulariser, HIP soft-argmin init, fused HIP loop with
     absolute coordinates) against the reference's forward on the same tiny backbone and weights."""
