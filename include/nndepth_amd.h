@@ -256,6 +256,10 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed_dev, con
                        int N, int D, int H, int W, float leaky_slope, void* stream);
 int nnd_volume_to_depth_major(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
 int nnd_depth_major_to_volume(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
+/* the same for a volume stored (N, C, H, W, D), candidate axis contiguous — level 0 of the IGEV pyramids, rows
+ * (b, g, h, w1) of w2 floats (igev_stereo/cost_volume.py:40-52): the regulariser reads / writes the pyramids in place */
+int nnd_volume_rows_to_depth_major(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
+int nnd_depth_major_to_volume_rows(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
 /* Upsampler3D's F.interpolate(scale_factor=2, mode="trilinear", align_corners=True) (cost_volume.py:128): depth-major
  * x (N,D+2,C,H,W) -> y (N,2D+2,C,2H,2W).  FeatureGuidedBlock (cost_volume.py:133-147): vol *= sigmoid(logits (N,C,H,W)),
  * broadcast over the depth slices, in place.                                                                              */

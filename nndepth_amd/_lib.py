@@ -88,6 +88,8 @@ SIGNATURES = {
     "nnd_conv3d_forward": (_I, [C.POINTER(Conv3dDesc), _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P]),
     "nnd_volume_to_depth_major": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_depth_major_to_volume": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_volume_rows_to_depth_major": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_depth_major_to_volume_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_volume_upsample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_volume_gate": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),

@@ -51,6 +51,14 @@ class GeometryAwareCostVolume:
         # torch.split(fmap, num_groups) yields chunks of num_groups channels; only the first num_groups are used (Q4)
         self._feat = ops.group_corr_build(fmap1.float(), fmap2.float(), num_groups, num_groups, num_levels)
         feat0 = self._feat[:B * num_groups * H * W * W].view(B, num_groups, H, W, W)
+        if getattr(regularizer_3d, "hip_active", lambda x: False)(feat0):
+            # nndepth_amd's regulariser on its HIP path reads the rows of the feature volume and writes the rows of the
+            # geometry volume straight into its pyramid buffer: no permuted copies either side
+            _, _, total = ops.pyramid_layout(B * num_groups, H, W, num_levels)
+            self._geo = torch.empty(total, dtype=torch.float32, device=feat0.device)
+            regularizer_3d.forward_rows(feat0, features, out=self._geo[:feat0.numel()].view(B, num_groups, H, W, W))
+            ops.pyramid_pool_levels_(self._geo, B * num_groups, H, W, num_levels)
+            return
         geo = regularizer_3d(feat0.clone().permute(0, 1, 4, 2, 3), features)          # (B, G, W2, H, W1)
         geo0 = geo.permute(0, 1, 3, 4, 2).contiguous().float()                          # (B, G, H, W1, W2)
         self._geo = ops.pyramid_from_level0(geo0.view(-1, W), B * num_groups, H, W, num_levels)

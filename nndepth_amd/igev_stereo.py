@@ -119,7 +119,16 @@ class CostVolumeFilterNetwork(nn.Module):
         self._hip, self._hip_version = e, v
         return e
 
-    def _forward_hip(self, x: torch.Tensor, features: List[torch.Tensor]) -> torch.Tensor:
+    def forward_rows(self, rows: torch.Tensor, features: List[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same network on a volume kept as the pyramids keep it, (B,G,H,W1,W2) with the candidate axis contiguous
+        (`forward(x)` with x = rows.permute(0,1,4,2,3)); the result, in the same layout, optionally written into `out`.
+        Used by GeometryAwareCostVolume to skip the permuted copies either side of the regulariser (HIP path only)."""
+        return self._forward_hip(rows, features, rows_layout=True, out=out)
+
+    def hip_active(self, x: torch.Tensor) -> bool:
+        return bool(self.hip and x.is_cuda and not self.training)
+
+    def _forward_hip(self, x: torch.Tensor, features: List[torch.Tensor], rows_layout: bool = False, out=None) -> torch.Tensor:
         e = self._engines(x.device)
         feats = [f.float() for f in features]
 
@@ -129,13 +138,14 @@ class CostVolumeFilterNetwork(nn.Module):
         def down(key, vol):
             a, b = e[key]
             return b(a(vol))
-        c1 = gated(down("conv1", ops.volume_to_depth_major(x.float())), e["g1"], feats[0])
+        x0 = ops.volume_rows_to_depth_major(x.float()) if rows_layout else ops.volume_to_depth_major(x.float())
+        c1 = gated(down("conv1", x0), e["g1"], feats[0])
         c2 = gated(down("conv2", c1), e["g2"], feats[1])
         c3 = gated(down("conv3", c2), e["g3"], feats[2])
         c2 = gated(e["proj_3"](e["conv3_up"](ops.volume_upsample2x(c3)), c2), e["g3u"], feats[1])
         c1 = gated(e["proj_2"](e["conv2_up"](ops.volume_upsample2x(c2)), c1), e["g2u"], feats[0])
-        out = e["final"](e["conv1_up"](ops.volume_upsample2x(c1)))
-        return ops.depth_major_to_volume(out)
+        y = e["final"](e["conv1_up"](ops.volume_upsample2x(c1)))
+        return ops.depth_major_to_volume_rows(y, out) if rows_layout else ops.depth_major_to_volume(y)
 
 
 # ------------------------------------------------------------------ the model

@@ -319,6 +319,14 @@ def pyramid_from_level0(level0: torch.Tensor, B: int, H: int, W: int, num_levels
     return pyr
 
 
+def pyramid_pool_levels_(pyr: torch.Tensor, B: int, H: int, W: int, num_levels: int) -> torch.Tensor:
+    """Levels 1..num_levels of a pyramid buffer whose level 0 is already in place (in-place variant of pyramid_from_level0)."""
+    d = _dev(pyr)
+    with torch.cuda.device(d):
+        check(lib.nnd_pyramid_from_level0(_p(pyr), B, H, W, num_levels, _stream(d)), "pyramid_from_level0")
+    return pyr
+
+
 def igev_lookup(feat_pyr: torch.Tensor, geo_pyr: torch.Tensor, coords: torch.Tensor, num_groups: int,
                 num_levels: int, radius: int) -> torch.Tensor:
     d = _dev(feat_pyr, geo_pyr, coords)
@@ -600,6 +608,32 @@ def depth_major_to_volume(x: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(d):
         check(lib.nnd_depth_major_to_volume(_p(x), _p(y), N, Cc, Dp - 2, H, W, _stream(d)), "depth_major_to_volume")
     return y
+
+
+def volume_rows_to_depth_major(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W,D) (candidate axis contiguous: the pyramid rows) -> (N,D+2,C,H,W) with zero end slices."""
+    d = _dev(x)
+    if not x.is_contiguous():
+        raise NndError("volume_rows_to_depth_major: contiguous (N,C,H,W,D) expected")
+    N, Cc, H, W, D = x.shape
+    y = torch.empty((N, D + 2, Cc, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_volume_rows_to_depth_major(_p(x), _p(y), N, Cc, D, H, W, _stream(d)), "volume_rows_to_depth_major")
+    return y
+
+
+def depth_major_to_volume_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(N,D+2,C,H,W) -> (N,C,H,W,D), optionally into `out` (e.g. level 0 of a pyramid buffer)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Dp, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, Cc, H, W, Dp - 2), dtype=torch.float32, device=d)
+    if not out.is_contiguous() or out.numel() != N * Cc * H * W * (Dp - 2) or out.dtype != torch.float32 or out.device != d:
+        raise NndError("depth_major_to_volume_rows: `out` must be a contiguous fp32 (N,C,H,W,D) tensor on the same device")
+    with torch.cuda.device(d):
+        check(lib.nnd_depth_major_to_volume_rows(_p(x), _p(out), N, Cc, Dp - 2, H, W, _stream(d)), "depth_major_to_volume_rows")
+    return out
 
 
 class Conv3dNorm:

@@ -828,3 +828,12 @@ def test_igev_regulariser_hip_golden(gold, name, B, H, W):
     err_pt = np.abs(cv_pt.geo_aware_cv[0][:, 0].cpu().numpy() - g[name + "_geo0"]).max()
     print(f"\nregulariser {name}: HIP vs reference {err:.2e}, PyTorch-ROCm vs reference {err_pt:.2e} (|geo| max {np.abs(g[name + '_geo0']).max():.2f})")
     assert err <= 2e-5
+    # cv above went through forward_rows (volume read / written in the pyramids' row layout); the module called the
+    # reference's way, on the permuted (B,G,W2,H,W1) volume, gives the same bits, and so do the pooled levels
+    reg.hip = True
+    feat0 = cv._feat[:B * 8 * H * W * W].view(B, 8, H, W, W)
+    with torch.no_grad():
+        geo_std = reg(feat0.clone().permute(0, 1, 4, 2, 3), guides).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(geo_std.view(-1, W), cv.geo_aware_cv[0][:, 0])
+    for lvl in range(1, 5):
+        assert torch.equal(cv.geo_aware_cv[lvl], torch.nn.functional.avg_pool1d(cv.geo_aware_cv[lvl - 1], 2, stride=2))
