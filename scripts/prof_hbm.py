@@ -57,7 +57,20 @@ def main():
     line("pyramid_from_level0 136x240 G=8 (incl. level-0 copy)", timeit(lambda: ops.pyramid_from_level0(lvl0, B * G, H, W, 4), 10), (lvl0.numel() + fp.numel()) * 4 / 1e6)
     coords = torch.arange(W, device=DEV).float().view(1, 1, 1, W).repeat(B, 1, H, 1) - 20 * torch.rand(B, 1, H, W, device=DEV)
     line("igev_lookup 136x240 (576 ch)", timeit(lambda: ops.igev_lookup(fp, gp, coords, G, 4, 4), 20), (3 * 576 + 1) * H * W * 4 / 1e6)
-    del fp, gp
+    il = ops.igev_interleave_pyramids(fp, gp, B, G, H, W, 4)
+    line("igev_interleave_pyramids 136x240 G=8 (levels 0-3)", timeit(lambda: ops.igev_interleave_pyramids(fp, gp, B, G, H, W, 4), 10), 2 * il.numel() * 4 / 1e6)
+    conv = torch.nn.Conv3d(G, 1, 3, 1, 1)
+    geo0 = gp[:B * G * H * W * W]
+    line("igev_init_disparity 136x240x240 (squeezer + soft-argmin)", timeit(lambda: ops.igev_init_disparity(geo0, conv.weight, conv.bias, B, G, H, W, W), 10),
+         (geo0.numel() + B * H * W) * 4 / 1e6)
+    rows = geo0.view(B, G, H, W, W)
+    dm = ops.volume_rows_to_depth_major(rows)
+    line("volume_rows_to_depth_major 8x136x240x240", timeit(lambda: ops.volume_rows_to_depth_major(rows), 10), (rows.numel() + dm.numel()) * 4 / 1e6)
+    line("depth_major_to_volume_rows 8x136x240x240", timeit(lambda: ops.depth_major_to_volume_rows(dm), 10), 2 * rows.numel() * 4 / 1e6)
+    half = torch.randn(B, 122, 16, H // 2, W // 2, device=DEV)
+    up = ops.volume_upsample2x(half)
+    line("volume_upsample2x 16ch 120x68x120 -> 240x136x240", timeit(lambda: ops.volume_upsample2x(half), 10), (half.numel() + up.numel()) * 4 / 1e6)
+    del fp, gp, il, dm, half, up
     # CREStereo @1080x1920 (config 5): 1/8 135x240, 1/16 67x120, 1/32 33x60, C=256
     for (H, W) in ((135, 240), (67, 120), (33, 60)):
         B, C = 1, 256
