@@ -179,6 +179,42 @@ def test_update_block_fullsize_vs_oracle(R):
         assert err <= 2e-5 * max(1.0, b.abs().max().item()), f"{nm}: {err}"
 
 
+def test_update_block_conv_gru_vs_oracle(R, ops):
+    """Row a7: the single 3x3 ConvGRU variant (gru="conv_gru", nndepth/blocks/gru.py:53-61; Coarse2Fine's update block):
+    one application of the block, then the fused loop (lookup -> block -> coords += delta -> upsample) for 3 iterations
+    against the same loop composed from the oracle's pieces."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    sd = weightgen.fill_state_dict(R.update_block_spec("update_block", 128, 36, 128, 1, 8, gru="conv_gru"))
+    ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=128, flow_channel=1, spatial_scale=8, gru="conv_gru")
+    ub.load_state_dict({k[len("update_block."):]: v for k, v in sd.items()})
+    ub = ub.to(DEV)
+    torch.manual_seed(31)
+    B, H, W, iters = 2, 20, 44, 3
+    net, inp = torch.tanh(torch.randn(B, 128, H, W)), torch.relu(torch.randn(B, 128, H, W))
+    corr, flow = torch.randn(B, 36, H, W), torch.randn(B, 1, H, W) * 4
+    got = ub(net.to(DEV), inp.to(DEV), corr.to(DEV), flow.to(DEV))
+    exp = R.update_block(sd, "update_block", net, inp, corr, flow, gru="conv_gru")
+    for a, b, nm in zip(got, exp, ("net", "mask", "delta")):
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b.abs().max().item()), f"{nm}: {err}"
+    # fused loop
+    f1, f2 = torch.randn(B, 64, H, W), torch.randn(B, 64, H, W)
+    pyr_ref = R.corr1d_build(f1, f2, 4)
+    org = torch.arange(W).float()[None, None, None].repeat(B, 1, H, 1)
+    c1, n, ups = org.clone(), net, []
+    for _ in range(iters):
+        n, m, d = R.update_block(sd, "update_block", n, inp, R.corr1d_lookup(pyr_ref, c1, 4, 4), c1 - org, gru="conv_gru")
+        c1 = c1 + d
+        ups.append(R.convex_upsample(c1 - org, m, 8))
+    pyr = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
+    up, low, n_out = ub.sync_engine(DEV).refine(pyr, 4, 4, net.to(DEV), inp.to(DEV), 8, iters)
+    for i in range(iters):
+        err = (up[i].cpu() - ups[i]).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ups[i].abs().max().item() / 40), f"iter {i}: {err}"
+    assert (n_out.cpu() - n).abs().max() <= 5e-5
+
+
 # ---------------------------------------------------------------------------------- full forward
 def _model(raft_sd, iters, fused=True):
     from nndepth_amd.raft_stereo import BaseRAFTStereo
