@@ -86,7 +86,7 @@ struct ConvIO {
 };
 
 // input channels per K-chunk for a layer shape (host packer and kernels must agree)
-int conv_ci_t(int KH, int KW, int Cin, int stride = 1);
+int conv_ci_t(int KH, int KW, int Cin, int stride = 1, int Cout = 0);
 
 int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi,
                 int B, int H, int W, hipStream_t stream);

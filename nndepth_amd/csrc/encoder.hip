@@ -43,7 +43,7 @@ static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total) {
                     "conv: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", d->KH, d->KW);
     ConvLayer l;
     l.KH = d->KH; l.KW = d->KW; l.Cin = d->Cin; l.Cout = d->Cout; l.stride = d->stride;
-    l.CI_T = conv_ci_t(d->KH, d->KW, d->Cin, d->stride);
+    l.CI_T = conv_ci_t(d->KH, d->KW, d->Cin, d->stride, d->Cout);
     l.nchunks = cdiv(d->Cin, l.CI_T);
     l.ncb = cdiv(d->Cout, 32);
     int64_t off = 0;

@@ -45,7 +45,7 @@ struct Plan {
 
 static ConvLayer mk(int KH, int KW, int Cin, int Cout, int64_t* off) {
     ConvLayer l;
-    const int CI_T = conv_ci_t(KH, KW, Cin);
+    const int CI_T = conv_ci_t(KH, KW, Cin, 1, Cout);
     l.KH = KH; l.KW = KW; l.Cin = Cin; l.Cout = Cout; l.CI_T = CI_T;
     l.nchunks = cdiv(Cin, CI_T);
     l.ncb = cdiv(Cout, 32);

@@ -45,6 +45,8 @@ def _unpack(blob, Cout, Cin, KH, KW):
     """Inverse of the documented A-fragment order [cb][chunk][tap][q][lane][j]."""
     NT = KH * KW
     CI_T = 128 if (KH == 1 and KW == 1 and Cin >= 128) else 32
+    if KH * KW == 5 and Cin >= 256 and Cout >= 256:
+        CI_T = 64  # wide GRU gate convs (csrc/conv_mfma.hip: conv_ci_t)
     NQ, nch, ncb = CI_T // 8, -(-Cin // CI_T), -(-Cout // 32)
     n = ncb * nch * NT * NQ * 256
     Wp = blob[:n].reshape(ncb, nch, NT, NQ, 2, 32, 4)  # cb, chunk, tap, q, h2, i, j
