@@ -15,6 +15,7 @@
 //
 // This file is compiled with -ffp-contract=off so the lookup reproduces the reference's
 // mul/mul/add rounding sequence bit for bit.
+#include <algorithm>
 #include "common.h"
 #include "layout.h"
 
@@ -116,6 +117,177 @@ __global__ void __launch_bounds__(256) corr1d_build_kernel(const float* __restri
             }
         }
     }
+}
+
+// Same result (same MFMA sequence per output, same pooling arithmetic: bit-identical) with both operands staged through
+// LDS and the output block written through LDS:
+//   * loads: the 32-channel chunk of the f1 block (32 columns) and of the whole f2 row are fetched with 16-byte coalesced
+//     loads into registers while the previous chunk is multiplied (the kernel above issues one 4-byte load per lane and
+//     MFMA operand, 2 per MFMA, and is bound by the load-issue rate: 0.53 TB/s at 68x120, 0.63 TB/s at batch 8);
+//   * stores: the 32 pyramid rows of a workgroup are contiguous in every level, so after pooling in LDS each level leaves
+//     as one linear coalesced copy (the kernel above stores 16 + 4x16 partial rows per tile from the accumulator layout).
+// grid (ceil(W/32), H, B*G), 256 threads; wave t multiplies the w2 tiles t, t+4, ... (NT of them).
+constexpr int CB_MAXLD = 12;
+template <int NT>
+__global__ void __launch_bounds__(256) corr1d_build_lds_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                               float* __restrict__ pyr, PyrLayout L, int C, int H, int W,
+                                                               float rscale_div, int Ctot, int G, int KC) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int w1_0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const long HW = (long)H * W;
+    const long chan0 = (long)(b / G) * Ctot + (long)(b % G) * C;
+    const float* a_base = f1 + chan0 * HW + (long)h * W;
+    const float* b_base = f2 + chan0 * HW + (long)h * W;
+    const int ntile = (W + 31) / 32, WP = ntile * 32;
+    float* sA = sm;             // [KC][32]
+    float* sB = sm + KC * 32;   // [KC][WP]
+    const bool vec = (W & 3) == 0;
+    const int UPC = 8 + WP / 4, nunits = KC * UPC;  // float4 units per channel: 8 of the f1 block, WP/4 of the f2 row
+    float4 st[CB_MAXLD];
+    int ucode[CB_MAXLD];  // chunk-invariant decomposition of this thread's units: channel << 16 | column << 1 | isA
+#pragma unroll
+    for (int k = 0; k < CB_MAXLD; ++k) {
+        const int u = tid + 256 * k, ch = u / UPC, r = u - ch * UPC;
+        ucode[k] = (ch << 16) | ((r < 8 ? 4 * r : 4 * (r - 8)) << 1) | (r < 8 ? 1 : 0);
+    }
+    auto unit = [&](int k, int& ch, int& col, bool& isA) {
+        ch = ucode[k] >> 16;
+        col = (ucode[k] & 0xffff) >> 1;
+        isA = ucode[k] & 1;
+    };
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < CB_MAXLD; ++k) {
+            const int u = tid + 256 * k;
+            if (u < nunits) {
+                int ch, col;
+                bool isA;
+                unit(k, ch, col, isA);
+                const int c = c0 + ch, gcol = isA ? w1_0 + col : col;
+                const float* src = (isA ? a_base : b_base) + (long)min(c, C - 1) * HW;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < C) {
+                    if (vec) {
+                        if (gcol < W) v = *reinterpret_cast<const float4*>(src + gcol);
+                    } else {
+                        if (gcol + 0 < W) v.x = src[gcol + 0];
+                        if (gcol + 1 < W) v.y = src[gcol + 1];
+                        if (gcol + 2 < W) v.z = src[gcol + 2];
+                        if (gcol + 3 < W) v.w = src[gcol + 3];
+                    }
+                }
+                st[k] = v;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < CB_MAXLD; ++k) {
+            const int u = tid + 256 * k;
+            if (u < nunits) {
+                int ch, col;
+                bool isA;
+                unit(k, ch, col, isA);
+                *reinterpret_cast<float4*>((isA ? sA + ch * 32 : sB + ch * WP) + col) = st[k];
+            }
+        }
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    const int nchunk = (C + KC - 1) / KC;
+    fetch(0);
+    for (int ck = 0; ck < nchunk; ++ck) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (ck + 1 < nchunk) fetch((ck + 1) * KC);
+        const int nstep = min(KC, C - ck * KC + 1) / 2;  // k-steps of 2 channels that hold real channels
+        // GS k-steps at a time with all their LDS reads issued before the first MFMA (at most 16 reads: lgkmcnt saturates at 15)
+        constexpr int GS = NT == 1 ? 8 : 1;  // measured: batching pays only with one tile per wave (68x120: 47.6 -> 34.8 us; 8x48x156: 245 -> 305 us)
+        for (int s0 = 0; s0 < nstep; s0 += GS) {
+            float av[GS], bv[GS][NT];
+#pragma unroll
+            for (int ss = 0; ss < GS; ++ss) {
+                const int row = (2 * min(s0 + ss, nstep - 1) + h2);
+                av[ss] = sA[row * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[ss][j] = sB[row * WP + min(wave + 4 * j, ntile - 1) * 32 + l31];
+            }
+#pragma unroll
+            for (int ss = 0; ss < GS; ++ss)
+                if (s0 + ss < nstep) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (wave + 4 * j < ntile) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ss], bv[ss][j], acc[j], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();  // the operand buffers become the output block: level 0 [32][W], level l behind it [32][W_l]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = wave + 4 * j, col = t * 32 + l31;
+        if (t < ntile && col < W)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) sm[((reg & 3) + 8 * (reg >> 2) + 4 * h2) * W + col] = acc[j][reg] / rscale_div;
+    }
+    __syncthreads();
+    int lo = 0;
+    for (int l = 1; l < L.nlev; ++l) {
+        const int wp = L.width[l - 1], wl = L.width[l];
+        const float* src = sm + lo;
+        float* dst = sm + lo + 32 * wp;
+        for (int idx = tid; idx < 32 * wl; idx += 256) {
+            const int i = idx / wl, jx = idx - i * wl;
+            dst[idx] = (src[i * wp + 2 * jx] + src[i * wp + 2 * jx + 1]) * 0.5f;
+        }
+        lo += 32 * wp;
+        __syncthreads();
+    }
+    const int nrows = min(32, W - w1_0);
+    const long prow0 = ((long)b * H + h) * W + w1_0;  // first pyramid row of the block
+    lo = 0;
+    for (int l = 0; l < L.nlev; ++l) {
+        const int wl = L.width[l];
+        float* g = pyr + L.off[l] + prow0 * wl;
+        for (int idx = tid; idx < nrows * wl; idx += 256) g[idx] = sm[lo + idx];
+        lo += 32 * wl;
+    }
+}
+
+// launches corr1d_build_lds_kernel when the shape fits its staging plan; false: the caller uses corr1d_build_kernel
+static bool corr1d_build_lds_launch(const float* f1, const float* f2, float* pyr, const PyrLayout& L, int C, int H, int W, int B,
+                                    float div, int Ctot, int G, hipStream_t stream, int* rc) {
+    const int ntile = cdiv(W, 32), WP = ntile * 32, NT = cdiv(ntile, 4);
+    int KC = C >= 32 ? 32 : ((C + 1) / 2) * 2;
+    if (C >= 64 && cdiv(64 * (8 + WP / 4), 256) <= CB_MAXLD) KC = 64;  // fewer, longer chunks: the next chunk's loads get more cover
+    if (NT > 4 || cdiv(KC * (8 + WP / 4), 256) > CB_MAXLD || getenv("NND_CORR_BUILD_V1")) return false;
+    long outf = 0;
+    for (int l = 0; l < L.nlev; ++l) outf += 32L * L.width[l];
+    const size_t lds = sizeof(float) * (size_t)std::max<long>((long)KC * (32 + WP), outf);
+    if (lds > 160 * 1024) return false;
+    dim3 grid(cdiv(W, 32), H, B * G), block(256);
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    if (!attr_set) {
+        const void* kerns[4] = {reinterpret_cast<const void*>(corr1d_build_lds_kernel<1>), reinterpret_cast<const void*>(corr1d_build_lds_kernel<2>),
+                                reinterpret_cast<const void*>(corr1d_build_lds_kernel<3>), reinterpret_cast<const void*>(corr1d_build_lds_kernel<4>)};
+        for (const void* k : kerns)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                *rc = NND_ERR_HIP;
+                return true;
+            }
+        attr_set = true;
+    }
+    if (NT == 1) hipLaunchKernelGGL(corr1d_build_lds_kernel<1>, grid, block, lds, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, KC);
+    else if (NT == 2) hipLaunchKernelGGL(corr1d_build_lds_kernel<2>, grid, block, lds, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, KC);
+    else if (NT == 3) hipLaunchKernelGGL(corr1d_build_lds_kernel<3>, grid, block, lds, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, KC);
+    else hipLaunchKernelGGL(corr1d_build_lds_kernel<4>, grid, block, lds, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, KC);
+    *rc = hipGetLastError() == hipSuccess ? NND_OK : NND_ERR_HIP;
+    return true;
 }
 
 struct LookupArgs {
@@ -601,6 +773,11 @@ int nnd_corr1d_build(const float* fmap1, const float* fmap2, float* pyramid, int
     make_layout(B, H, W, num_levels + 1, &L, nullptr);
     dim3 grid(cdiv(W, 32), H, B), block(256);
     float div = (float)sqrt((double)C);
+    int rc_lds = NND_OK;
+    if (corr1d_build_lds_launch(fmap1, fmap2, pyramid, L, C, H, W, B, div, C, 1, (hipStream_t)stream, &rc_lds)) {
+        if (rc_lds != NND_OK) set_error("corr1d_build: launch failed");
+        return rc_lds;
+    }
     if (C >= 64)
         hipLaunchKernelGGL(corr1d_build_kernel<32>, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, C, H, W, div, C, 1);
     else
@@ -619,6 +796,11 @@ int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid,
     make_layout(B * num_groups, H, W, num_levels + 1, &L, nullptr);
     dim3 grid(cdiv(W, 32), H, B * num_groups), block(256);
     float div = (float)sqrt((double)group_channels);
+    int rc_lds = NND_OK;
+    if (corr1d_build_lds_launch(fmap1, fmap2, pyramid, L, group_channels, H, W, B, div, Ctot, num_groups, (hipStream_t)stream, &rc_lds)) {
+        if (rc_lds != NND_OK) set_error("group_corr_build: launch failed");
+        return rc_lds;
+    }
     if (group_channels >= 64)
         hipLaunchKernelGGL(corr1d_build_kernel<32>, grid, block, 0, (hipStream_t)stream, fmap1, fmap2, pyramid, L, group_channels,
                            H, W, div, Ctot, num_groups);
