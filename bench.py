@@ -123,7 +123,9 @@ def main():
             rows.append({"conv": nm, "ms": ms, "gflop": fl / 1e9, "tflops": fl / ms / 1e9})
             tot_ms += ms
             tot_fl += fl
-        dom = max(rows, key=lambda r: r["ms"])
+        # dominant launch = most algorithmic FLOPs (ties -> the first, encoder.convc2: also the longest one inside the loop);
+        # picking by measured time would flip between convc2 and flow_head.conv1+mask.0 (same FLOPs, 62 vs 64 us) on noise
+        dom = max(rows, key=lambda r: round(r["gflop"], 3))
         result["roofline"] = {
             "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2) — " + dom["conv"],
             "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
