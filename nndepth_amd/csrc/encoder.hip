@@ -5,7 +5,7 @@
 // cnet_proj conv of nndepth/models/raft_stereo/model.py:53-55 (reference; restated in oracle/torch_ref.py:
 // basic_encoder / residual_block).
 //
-//   conv1 7x7 s2 (3 -> 64) + norm + ReLU            stem_kernel (VALU: Cin = 3 is too shallow for the MFMA path)
+//   conv1 7x7 s2 (3 -> 64) + norm + ReLU            stem_kernel (its own implicit GEMM on the MFMA: K = 147 is too ragged for conv_mfma)
 //   6 residual blocks                                conv_mfma, 3 launches per block:
 //       y  = ReLU(norm1(conv1 3x3 (stride s)(x)))        EPI_AFFINE | relu
 //       sc = norm3(conv 1x1 (stride s)(x))               EPI_AFFINE
@@ -95,46 +95,80 @@ static int run_conv_norm(const ConvLayer& L, const float* base, const float* x, 
 }
 
 // ------------------------------------------------------------------------------------------ stem: 7x7 stride 2, 3 -> 64
-// One workgroup = a 8x32 output region (walked as 8 sub-tiles of 4x8, so a wave stores two 128-B lines of the
-// tile-major layout) x 32 of the 64 output channels.  The 3 x 21 x 69 input patch is staged in LDS; a thread keeps its
-// 147-tap neighbourhood in registers and the (wave-uniform) weights stream through the scalar cache.
-// grid (regions, 2 channel halves, N)
+// Implicit GEMM on the fp32 MFMA with K = 3*7*7 = 147 (+1 zero row): one workgroup = an 8x32 output region (8 sub-tiles of
+// 4x8 pixels, tile-major stores of two 128-B lines per wave and channel) x all 64 output channels; wave w multiplies
+// sub-tiles 2w, 2w+1 against both 32-channel blocks (4 accumulators).  The 3 x 21 x 69 input patch and the weights,
+// pre-transposed on the host to [k][co], sit in LDS: the A operand a[k][co] is a conflict-free row read, the B operand of
+// tap k = (c, dy, dx) for lane (r, cc) is patch[c][2r + dy][2cc + dx] — lane stride 2 / 144 floats, 32 distinct banks.
+// (The VALU version this replaces kept the 147 taps in registers and streamed the weights through the scalar cache:
+// 144 us for 2 x 544x960 frames; K is too ragged for conv_mfma's chunked staging.)
+// grid (regions, 1, N)
+constexpr int STEM_K = 148;  // 147 taps + one zero row
+typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ out, long obs, int Hin, int Win, int H, int W,
                                                    int tiles_x, Lay lay, int relu) {
-    __shared__ float patch[3][21][72];
-    const int tid = threadIdx.x;
+    __shared__ float patch[3 * 21 * 72];
+    __shared__ float wl[STEM_K * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
     const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
-    const int n = blockIdx.z, co0 = blockIdx.y * 32;
+    const int n = blockIdx.z;
     const long HWin = (long)Hin * Win;
     const float* src = x + (long)n * 3 * HWin;
     for (int e = tid; e < 3 * 21 * 69; e += 256) {
         const int c = e / (21 * 69), rem = e % (21 * 69);
         const int pr = rem / 69, pc = rem % 69;
         const int gy = ty0 * 2 + pr - 3, gx = tx0 * 2 + pc - 3;
-        patch[c][pr][pc] = (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) ? src[c * HWin + (long)gy * Win + gx] : 0.f;
+        patch[(c * 21 + pr) * 72 + pc] = (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) ? src[c * HWin + (long)gy * Win + gx] : 0.f;
     }
+    for (int e = tid; e < STEM_K * 16; e += 256) reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(w)[e];
     __syncthreads();
-    const int st = tid >> 5, within = tid & 31;
-    const int ty = (st >> 2) * 4 + (within >> 3), tx = (st & 3) * 8 + (within & 7);
-    float v[147];
+    stem_f32x16 acc[2][2];  // [sub-tile of the wave][channel block]
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int dy = 0; dy < 7; ++dy)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int dx = 0; dx < 7; ++dx) v[c * 49 + dy * 7 + dx] = patch[c][2 * ty + dy][2 * tx + dx];
-    const int y = ty0 + ty, xx = tx0 + tx;
-    const bool ok = y < H && xx < W;
-    float* o = out + (long)n * obs + (ok ? pix_off(lay, y, xx) : 0);
-    for (int co = co0; co < co0 + 32; ++co) {
-        const float* wc = w + (long)co * 147;
-        float acc = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // lane base of the B operand for the wave's two sub-tiles: st = 2*wave + i -> rows (st>>2)*4 + r, cols (st&3)*8 + cc
+    const int r = l31 >> 3, cc = l31 & 7;
+    int base[2];
 #pragma unroll
-        for (int i = 0; i < 147; ++i) acc = fmaf(wc[i], v[i], acc);
-        acc = fmaf(acc, scale[co], shift[co]);
-        if (ok) o[(long)co * lay.plane] = relu ? fmaxf(acc, 0.f) : acc;
+    for (int i = 0; i < 2; ++i) {
+        const int st = 2 * wave + i;
+        base[i] = (2 * ((st >> 2) * 4 + r)) * 72 + 2 * ((st & 3) * 8 + cc);
+    }
+#pragma unroll
+    for (int kp = 0; kp < STEM_K / 2; ++kp) {
+        // tap offsets of k = 2kp and 2kp + 1 inside the patch (compile-time), selected by the lane's k parity
+        const int k0 = 2 * kp, k1 = 2 * kp + 1;
+        const int o0 = (k0 / 49 * 21 + (k0 % 49) / 7) * 72 + k0 % 7;
+        const int o1 = k1 < 147 ? (k1 / 49 * 21 + (k1 % 49) / 7) * 72 + k1 % 7 : 0;  // k = 147: zero weight row, any address
+        const int off = h2 ? o1 : o0;
+        const float a0 = wl[(2 * kp + h2) * 64 + l31], a1 = wl[(2 * kp + h2) * 64 + 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float bv = patch[base[i] + off];
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[i][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int st = 2 * wave + i;
+        const int y = ty0 + (st >> 2) * 4 + r, xx = tx0 + (st & 3) * 8 + cc;
+        if (y >= H || xx >= W) continue;
+        float* o = out + (long)n * obs + pix_off(lay, y, xx);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = j * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                const float v = fmaf(acc[i][j][reg], scale[co], shift[co]);
+                o[(long)co * lay.plane] = relu ? fmaxf(v, 0.f) : v;
+            }
     }
 }
 
@@ -228,7 +262,7 @@ static int in_apply(float* x, int64_t bs, const float* stats, const float* sc, i
 constexpr int ENC_BLOCKS = 6;
 struct EncPlan {
     nnd_encoder_desc d;
-    int64_t stem_w, stem_scale, stem_shift;  // raw (64,3,7,7) weights + folded norm
+    int64_t stem_w, stem_scale, stem_shift;  // (64,3,7,7) weights transposed to [k = c*49 + dy*7 + dx (148 rows, last zero)][co] + folded norm
     ConvLayer c1[ENC_BLOCKS], c2[ENC_BLOCKS], ds[ENC_BLOCKS];
     int64_t base1[ENC_BLOCKS], base2[ENC_BLOCKS], based[ENC_BLOCKS];
     ConvLayer out;  // conv2 1x1
@@ -245,7 +279,7 @@ static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
     NND_REQUIRE(d->norm >= 0 && d->norm <= 2, "encoder: norm must be 0 (none), 1 (batch, eval) or 2 (instance); group norm is not built");
     p->d = *d;
     int64_t off = 0;
-    p->stem_w = off; off += 64 * 147;
+    p->stem_w = off; off += STEM_K * 64;
     p->stem_scale = off; off += 64;
     p->stem_shift = off; off += 64;
     const int dims[3] = {64, 96, 128}, strd[3] = {1, 2, 2};
@@ -359,7 +393,8 @@ int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* t, float 
     auto unit = [&](int u) { return t + 6 * u; };
     {  // stem: raw weights + folded norm
         const float* const* q = unit(0);
-        memcpy(packed_host + p.stem_w, q[0], sizeof(float) * 64 * 147);
+        for (int co = 0; co < 64; ++co)
+            for (int k = 0; k < 147; ++k) packed_host[p.stem_w + (int64_t)k * 64 + co] = q[0][co * 147 + k];  // row 147 stays zero
         for (int c = 0; c < 64; ++c) {
             double sc = 1.0, sh = q[1][c];
             if (q[2]) {
@@ -410,7 +445,7 @@ int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const
     {  // stem -> buf[0]
         const Lay lay = make_lay(h, w, true);
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 8);
-        hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 2, N), dim3(256), 0, s, frames, packed + p.stem_w,
+        hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 1, N), dim3(256), 0, s, frames, packed + p.stem_w,
                            packed + p.stem_scale, packed + p.stem_shift, buf[0], (long)(64 * lay.plane), H, W, h, w, tiles_x, lay,
                            inorm ? 0 : 1);
         NND_LAUNCH_CHECK();

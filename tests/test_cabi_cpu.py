@@ -168,7 +168,9 @@ def test_encoder_pack_host(raft_sd):
     cnet_sd = {k[len("cnet_proj."):]: v for k, v in raft_sd.items() if k.startswith("cnet_proj.")}
     eng.load(enc_sd, cnet_sd, device="cpu")  # host-only packing
     assert eng.packed.numel() == eng.packed_floats and torch.isfinite(eng.packed).all()
-    assert torch.equal(eng.packed[:64 * 147].view(64, 3, 7, 7), enc_sd["conv1.weight"])  # stem weights kept raw
+    # stem weights: transposed to [k = c*49 + dy*7 + dx][co] with one zero row (K = 148) for the MFMA stem kernel
+    stem = eng.packed[:148 * 64].view(148, 64)
+    assert torch.equal(stem[:147].t().reshape(64, 3, 7, 7), enc_sd["conv1.weight"]) and not stem[147].any()
     assert lib.nnd_encoder_workspace_floats(C.byref(eng.desc), 2, 544, 960) == 4 * 2 * 64 * 272 * 480
     with pytest.raises(NndError):
         ops.EncoderEngine(256, "group", 0)
