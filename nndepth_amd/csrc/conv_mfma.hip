@@ -461,7 +461,9 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(ConvArgs a, int nti
     }
     const int tend = min(t0 + TPW, ntiles);
     for (int t = t0; t < tend; ++t) {
-        const float* src = a.src0 + b * a.bs0 + (long)t * 32 + l31;
+        const int y = (t / a.tiles_x) * 4 + (l31 >> 3), x = (t % a.tiles_x) * 8 + (l31 & 7);
+        const bool pix_ok = y < a.H && x < a.W;
+        const float* src = a.src0 + b * a.bs0 + (pix_ok ? pix_off(a.ls, y, x) : 0);  // tile-major: t*32 + l31, one line per channel
         float bv[NQ * 4];
 #pragma unroll
         for (int kp = 0; kp < NQ * 4; ++kp) bv[kp] = src[(long)(2 * kp + h2) * SP];
@@ -474,9 +476,8 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(ConvArgs a, int nti
             const float a_s = (kp % 4 == 0) ? av.x : (kp % 4 == 1) ? av.y : (kp % 4 == 2) ? av.z : av.w;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, bv[kp], acc, 0, 0, 0);
         }
-        const int y = (t / a.tiles_x) * 4 + (l31 >> 3), x = (t % a.tiles_x) * 8 + (l31 & 7);
-        if (y >= a.H || x >= a.W) continue;
-        const long pix = (long)t * 32 + l31;
+        if (!pix_ok) continue;
+        const long pix = pix_off(a.ld, y, x);
         float res[16];
         if (epi == EPI_AFFINE && a.aux0) {
 #pragma unroll
@@ -635,7 +636,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;
     a.scale = io.scale;
     static const bool no_stream = getenv("NND_NO_CONV1X1_STREAM") != nullptr;
-    if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && io.dst_tiled && !io.bmap.ptr &&
+    if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && !io.bmap.ptr &&
         (L.Cin == 64 || L.Cin == 96 || L.Cin == 128) &&
         (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_SCALE || epi == EPI_AFFINE)) {
         const int ntiles = cfg.tiles_x * cfg.tiles_y, KQ = L.nchunks * L.CI_T / 8;
