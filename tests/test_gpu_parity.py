@@ -574,7 +574,7 @@ def test_conv_norm_vs_torch(Cout, Cin, K, stride, B, H, W):
     assert (got - torch.relu(res + torch.relu(ref_bn))).abs().max() <= 3e-5
 
 
-@pytest.mark.parametrize("H,W,B", [(96, 160, 1), (120, 200, 2)])
+@pytest.mark.parametrize("H,W,B", [(96, 160, 1), (120, 200, 2), (99, 161, 1)])
 def test_encoder_small_vs_oracle(raft_sd, R, H, W, B):
     """BasicEncoder + cnet_proj in HIP against the oracle restatement (eval BatchNorm), small shapes incl. sizes that
     are not multiples of 8 at the lower levels."""
