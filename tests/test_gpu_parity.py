@@ -386,14 +386,15 @@ def test_igev_cost_volume_class_vs_oracle(R):
     assert tuple(got.shape) == (B, 576, H, W) and (got.cpu() - exp).abs().max() <= 5e-4
 
 
-def test_igev_refine_loop_vs_oracle(R):
+@pytest.mark.parametrize("B,H,W", [(1, 16, 40), (2, 10, 36)])  # 20 sub-tiles; 2 x 15 (odd count, ragged rows and columns)
+def test_igev_refine_loop_vs_oracle(R, B, H, W):
     """a16 (loop part): IGEV refinement — combined lookup, hidden 64 / cor_planes 576 update block, absolute
     coordinates into the update block and the rate-4 upsample (Q5) — one C-ABI call vs the oracle."""
     from nndepth_amd import weightgen, ops
     from nndepth_amd.blocks import BasicUpdateBlock
     from nndepth_amd.cost_volume import GeometryAwareCostVolume
     torch.manual_seed(21)
-    B, C, H, W, G, iters = 1, 128, 16, 40, 8, 3
+    C, G, iters = 128, 8, 3
     f1, f2 = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
     net, inp = torch.tanh(torch.randn(B, 64, H, W)), torch.relu(torch.randn(B, 64, H, W))
     init = -torch.rand(B, 1, H, W) * 6
