@@ -104,6 +104,23 @@ def test_corr1d_edge_cases(ops):
         assert (mine - ref[i][:, 0]).abs().max() <= 2e-6
     with pytest.raises(Exception):
         ops.corr1d_build(f1, f2, 4)  # CPU tensors must be refused, not silently computed
+    # wide rows: 3 and 4 w2 tiles per wave of the LDS-staged kernel, then (W > 512) the register-operand kernel; the
+    # LDS-staged and the register-operand kernel must agree bit for bit (same MFMA sequence, same pooling arithmetic)
+    import os
+    for (B, C, H, W) in ((1, 8, 2, 300), (1, 6, 1, 500), (1, 4, 1, 520), (2, 64, 3, 156)):
+        f1, f2 = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+        pyr = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
+        ref = R.corr1d_build(f1, f2, 4)
+        offs, widths, _ = ops.pyramid_layout(B, H, W, 4)
+        for i, (o, w) in enumerate(zip(offs, widths)):
+            mine = pyr[o:o + B * H * W * w].view(-1, w).cpu()
+            assert (mine - ref[i][:, 0]).abs().max() <= 5e-6, (B, C, H, W, i)
+        os.environ["NND_CORR_BUILD_V1"] = "1"
+        try:
+            v1 = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
+        finally:
+            del os.environ["NND_CORR_BUILD_V1"]
+        assert torch.equal(v1, pyr), (B, C, H, W)
 
 
 # ------------------------------------------------------------------------------------ upsample
