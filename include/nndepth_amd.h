@@ -14,8 +14,18 @@
  *   - all work is enqueued on the caller-supplied hipStream_t (`stream`, may be NULL);
  *   - return value: 0 on success, negative nnd_status on failure (never throws);
  *     nnd_last_error() gives a thread-local message for the last failure;
- *   - no global mutable state except two lazily created, mutex-guarded side streams (+4 events) per device
- *     that nnd_raft_stereo_refine forks from / joins back into the caller's stream with events.
+ *   - threading: every entry point may be called concurrently from several host threads as long as the calls
+ *     use distinct streams and distinct output / workspace buffers.  The only mutable global state is a
+ *     mutex-guarded per-device pool of idle low-priority side streams: each nnd_*_stereo_refine call draws one
+ *     stream from it, creates its own two fork/join events, and joins the side stream back into the caller's
+ *     stream before returning — on error returns too — so no work that touches the caller's buffers is ever left
+ *     un-ordered behind `stream`;
+ *   - diagnostic environment switches (read per call; they select between kernels that the parity tests prove
+ *     equivalent, never a non-HIP path): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
+ *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
+ *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_CONV_CFG / NND_CONV_P
+ *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
+ *     (synchronise and name every launch of the update block on stderr).
  */
 #ifndef NNDEPTH_AMD_H
 #define NNDEPTH_AMD_H

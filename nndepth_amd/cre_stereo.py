@@ -24,10 +24,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from ._lib import NndError
 from .blocks import BasicUpdateBlock
 from .cost_volume import AGCL
 from .encoder import BasicEncoder
-from .raft_stereo import load_weights
+from .raft_stereo import hip_encoder_blocker, load_weights, require_eval
 from .upsample import convex_upsample
 
 
@@ -155,7 +156,11 @@ class CREStereoBase(nn.Module):
     def forward_fnet(self, frame1: torch.Tensor, frame2: torch.Tensor):
         """fnet([frame1, frame2]) (model.py:139); on the GPU at inference the instance-norm encoder runs in HIP
         (csrc/encoder.hip, norm = instance: raw convs + per-sample statistics + one fused apply pass per block)."""
-        if self.hip_encoder and frame1.is_cuda and not self.training and self.fnet.dropout is None:
+        if self.hip_encoder:
+            why = hip_encoder_blocker(self.fnet, ("instance", "batch", "none"))
+            if why:
+                raise NndError(f"CREStereoBase: the HIP encoder cannot run this fnet ({why}); pass hip_encoder=False to run "
+                               "the encoder's PyTorch-ROCm modules explicitly")
             tensors = list(self.fnet.state_dict().values())
             v = (tuple((t.data_ptr(), t._version) for t in tensors), str(frame1.device))
             if v != self._enc_version:
@@ -166,7 +171,7 @@ class CREStereoBase(nn.Module):
             B = frame1.shape[0]
             fmaps, _ = self._enc_engine.forward(torch.cat([frame1, frame2], 0).float())
             return fmaps[:B], fmaps[B:]
-        return self.fnet([frame1, frame2])
+        return self.fnet([frame1, frame2])  # explicit opt-in (hip_encoder=False): PyTorch-ROCm modules
 
     def _stage(self, corr_fn, net, inp, flow, offset, n_iters: int, iter_mode: bool, outs: List[Dict[str, torch.Tensor]]):
         if self.fused_loop and isinstance(corr_fn, AGCL) and n_iters > 0:
@@ -186,9 +191,13 @@ class CREStereoBase(nn.Module):
             outs.append({"up_disp": up})
         return net, flow, up
 
-    @torch.no_grad()
     def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, flow_init: Optional[torch.Tensor] = None,
                 upsample: bool = True, test_mode: bool = False, **kwargs):
+        require_eval(self)
+        with torch.no_grad():
+            return self._forward(frame1, frame2, flow_init)
+
+    def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor, flow_init: Optional[torch.Tensor] = None):
         frame1, frame2 = frame1.contiguous(), frame2.contiguous()
         hd, ds = self.hidden_dim, self.fnet_ds
         fmap1, fmap2 = self.forward_fnet(frame1, frame2)

@@ -10,8 +10,7 @@
 // workspace buffer (hx = [h | inp | motion | flow], cf = [cor | flo], fm = [flow_head.conv1 | mask.0]) and the
 // convolutions write straight into their channel slice.  convz/convr are packed as one 2*hidden-channel
 // conv whose epilogue emits z and r*h; convq's epilogue does the GRU blend in place.  In the fused loop the
-// flow branch (convf1 -> convf2) and the mask branch (mask.0 -> mask.2 -> convex upsample, which only feeds the
-// output) run on two side streams beside the critical path (see Streams / run_iteration).
+// flow branch (convf1 -> convf2) runs on a side stream beside the critical path (see ForkJoin / enqueue_refine).
 #include "common.h"
 #include "layout.h"
 
@@ -422,31 +421,63 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     return debug_sync("flow_head.conv2", s);
 }
 
-// Side streams + events for the fused loop.  Created once per device on first use (the only mutable global
-// state of the library); all cross-stream edges are explicit events, the caller's stream is joined at the end.
-struct Streams {
-    hipStream_t a = nullptr;            // flow branch of the motion encoder (convf1, convf2)
-    hipEvent_t f2 = nullptr, adv = nullptr;
-    bool ok = false;
+// Fork / join state of ONE fused-loop call.  The flow branch of the motion encoder runs on a low-priority side stream
+// beside the recurrence on the caller's stream; all cross-stream edges are explicit events.  Everything here is per call:
+// the two events are created by the call and destroyed when it returns, and the side stream is drawn from a per-device pool
+// (the only mutable global state of the library, mutex-guarded) and handed back after the join — so host threads that drive
+// distinct caller streams of one device never share a side stream or an event while they enqueue (include/nndepth_amd.h,
+// threading contract).  The destructor joins the side stream back into the caller's stream on EVERY exit path, error
+// returns included: nothing that references the caller's workspace is left un-ordered behind the caller's stream.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[16];
 };
-static Streams* side_streams() {
-    static Streams st[16];
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    Streams& s = st[dev];
-    if (!s.ok) {
-        // lowest priority: the side branch only fills the bubbles of the recurrence on the caller's stream
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-        if (hipStreamCreateWithPriority(&s.a, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-        for (hipEvent_t* e : {&s.f2, &s.adv})
-            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        s.ok = true;
-    }
-    return &s;
+static StreamPool& stream_pool() {
+    static StreamPool p;
+    return p;
 }
+struct ForkJoin {
+    hipStream_t caller = nullptr, a = nullptr;  // a: flow branch (convf1, convf2)
+    hipEvent_t f2 = nullptr, adv = nullptr;
+    int dev = -1;
+    bool forked = false;
+    int open(hipStream_t s) {
+        caller = s;
+        // the device that owns the caller's stream (the NULL stream belongs to the current device)
+        if (s == nullptr || hipStreamGetDevice(s, &dev) != hipSuccess) NND_HIP_CHECK(hipGetDevice(&dev));
+        NND_REQUIRE(dev >= 0 && dev < 16, "refine: device ordinal %d outside the side-stream pool", dev);
+        {
+            StreamPool& p = stream_pool();
+            std::lock_guard<std::mutex> lock(p.mu);
+            if (!p.idle[dev].empty()) {
+                a = p.idle[dev].back();
+                p.idle[dev].pop_back();
+            }
+        }
+        if (!a) {
+            // lowest priority: the side branch only fills the bubbles of the recurrence on the caller's stream
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            NND_HIP_CHECK(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, least));
+        }
+        NND_HIP_CHECK(hipEventCreateWithFlags(&f2, hipEventDisableTiming));
+        NND_HIP_CHECK(hipEventCreateWithFlags(&adv, hipEventDisableTiming));
+        return NND_OK;
+    }
+    ~ForkJoin() {
+        if (a && forked && f2) {  // join: whatever is still queued on the side stream precedes the caller's next work
+            if (hipEventRecord(f2, a) == hipSuccess) (void)hipStreamWaitEvent(caller, f2, 0);
+        }
+        // destroying an event with a pending record / wait is legal: its resources are released once it completes
+        if (f2) (void)hipEventDestroy(f2);
+        if (adv) (void)hipEventDestroy(adv);
+        if (a) {
+            StreamPool& p = stream_pool();
+            std::lock_guard<std::mutex> lock(p.mu);
+            p.idle[dev].push_back(a);
+        }
+    }
+};
 
 // One application of the update block on workspace state: expects h/inp/flow already in w.hx,
 // `flow` = (B,fc,H,W) dense.  Writes new h into w.hx[0:hid], delta, and (optionally) the mask.  Single stream.
@@ -686,13 +717,15 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     // captured into a hipGraph 17.6 | the 3-stream DAG as a hipGraph 34.  The kernels of one iteration already fill the
     // chip (sum of the stand-alone kernel times = in-loop time), so more streams buy no overlap and every event
     // record / wait on M costs a ~7 us bubble.
-    Streams* st = side_streams();
-    NND_REQUIRE(st, "refine: could not create the side stream");
+    ForkJoin fj;
+    NND_TRY(fj.open(s));
+    ForkJoin* st = &fj;
     const bool no_fuse_up = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;  // read per call: the parity tests toggle these
     const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     const bool fused_lk = !cre && !no_fuse_lk;
     NND_HIP_CHECK(hipEventRecord(st->adv, s));
+    st->forked = true;
     for (int it = 0; it < iters; ++it) {
         NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
         NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, st->a));
@@ -729,7 +762,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(convex_upsample_launch(w.flow, w.mask, up_it, B, fc, H, W, rate, s, true));
         }
     }
-    NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));  // join A (its last result was consumed already; keeps the contract simple)
+    // (the side stream is joined back into `s` by ~ForkJoin; its last result was consumed already)
     if (low_out) NND_TRY(from_tiled(w.flow, fc * n, low_out, B, fc, H, W, s));
     if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
     return NND_OK;

@@ -22,10 +22,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import warnings
+
 from . import ops
+from ._lib import NndError
 from .blocks import BasicUpdateBlock
 from .cost_volume import GeometryAwareCostVolume
-from .raft_stereo import load_weights
+from .raft_stereo import load_weights, require_eval
 from .upsample import convex_upsample
 
 
@@ -80,7 +83,8 @@ class CostVolumeFilterNetwork(nn.Module):
         self._hip, self._hip_version = None, None
 
     def forward(self, x: torch.Tensor, features: List[torch.Tensor]) -> torch.Tensor:
-        if self.hip and x.is_cuda and not self.training:
+        if self.hip:  # no silent fallback: `.hip = False` is the explicit opt-in to the PyTorch ops below
+            require_eval(self)
             return self._forward_hip(x, features)
 
         def down(seq, t):
@@ -126,7 +130,9 @@ class CostVolumeFilterNetwork(nn.Module):
         return self._forward_hip(rows, features, rows_layout=True, out=out)
 
     def hip_active(self, x: torch.Tensor) -> bool:
-        return bool(self.hip and x.is_cuda and not self.training)
+        if self.hip:
+            require_eval(self)
+        return bool(self.hip)
 
     def _forward_hip(self, x: torch.Tensor, features: List[torch.Tensor], rows_layout: bool = False, out=None) -> torch.Tensor:
         e = self._engines(x.device)
@@ -198,8 +204,12 @@ class IGEVStereoBase(nn.Module):
     def convex_upsample(self, flow, mask, rate=4):
         return convex_upsample(flow, mask, rate)
 
-    @torch.no_grad()
     def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
+        require_eval(self)
+        with torch.no_grad():
+            return self._forward(frame1, frame2)
+
+    def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
         fmap1, fmap2, cnet1, guide_features = self.forward_fnet(frame1, frame2)
         fnet_ds = frame1.shape[-1] // fmap1.shape[-1]
         fmap1, fmap2 = fmap1.float(), fmap2.float()
@@ -210,12 +220,17 @@ class IGEVStereoBase(nn.Module):
         B, _, H1, W1 = fmap1.shape
         W2 = fmap2.shape[-1]
         geo0 = corr.geo_aware_cv[0]
-        if geo0.is_cuda and ops.igev_init_disparity_supported(self.cv_groups, W2):
+        if ops.igev_init_disparity_supported(self.cv_groups, W2):
             # cv_squeezer + softmax + regress_disparity as one kernel over the volume where it lies
             init = ops.igev_init_disparity(geo0, *self._squeezer_host(), B, self.cv_groups, H1, W1, W2)
         else:
+            # shapes the fused kernel is not built for (more than 8 groups or 512 candidates): the squeezer runs as a
+            # PyTorch-ROCm Conv3d, the soft-argmin in HIP — said once, never silently
+            warnings.warn(f"IGEVStereoBase: cv_groups={self.cv_groups} / {W2} candidates are outside the fused squeezer + "
+                          "soft-argmin kernel (<= 8 groups, <= 512 candidates); the squeezer Conv3d runs on PyTorch-ROCm",
+                          RuntimeWarning, stacklevel=2)
             logits = self.cv_squeezer(geo0.reshape(B, self.cv_groups, H1, W1, W2).permute(0, 1, 4, 2, 3)).squeeze(1)
-            init = ops.softargmin_disparity(logits.float()) if logits.is_cuda else self.regress_disparity(F.softmax(logits, dim=1), W1)
+            init = ops.softargmin_disparity(logits.float())
         if self.fused_loop and isinstance(corr, GeometryAwareCostVolume):
             eng = self.update_block.sync_engine(frame1.device)
             up, _, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,

@@ -175,6 +175,17 @@ class UpdateBlockEngine:
             self._ws = torch.zeros(n, dtype=torch.float32, device=device)
         return self._ws
 
+    def _check_state(self, what: str, net, inp, init, init_channels: int):
+        """Shapes the C-ABI cannot see (it receives raw pointers): a wrong one would be an out-of-bounds device access."""
+        ds = self.desc
+        B, _, H, W = net.shape
+        if tuple(net.shape) != (B, ds.hidden_dim, H, W):
+            raise NndError(f"{what}: net shape {tuple(net.shape)} != {(B, ds.hidden_dim, H, W)}")
+        if tuple(inp.shape) != (B, ds.context_dim, H, W):
+            raise NndError(f"{what}: inp shape {tuple(inp.shape)} != {(B, ds.context_dim, H, W)}")
+        if init is not None and tuple(init.shape) != (B, init_channels, H, W):
+            raise NndError(f"{what}: initial disparity / flow shape {tuple(init.shape)} != {(B, init_channels, H, W)}")
+
     # ---- ops
     def forward(self, net, inp, corr, flow, want_mask: bool = True):
         if self.packed is None:
@@ -206,6 +217,12 @@ class UpdateBlockEngine:
         d = _dev(pyr, net, inp, self.packed)
         net, inp = net.contiguous(), inp.contiguous()
         B, _, H, W = net.shape
+        self._check_state("refine", net, inp, disp_init, 1)
+        if pyr.numel() != pyramid_layout(B, H, W, num_levels)[2]:
+            raise NndError(f"refine: pyramid holds {pyr.numel()} floats, a {B}x{H}x{W} pyramid of {num_levels} levels has "
+                           f"{pyramid_layout(B, H, W, num_levels)[2]}")
+        if disp_init is not None:
+            _dev(disp_init)
         n_up = iters if keep_all else 1
         up = torch.empty((n_up, B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
         low = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
@@ -229,6 +246,18 @@ class UpdateBlockEngine:
         d = _dev(feat_pyr, geo_pyr, net, inp, self.packed)
         net, inp = net.contiguous(), inp.contiguous()
         B, _, H, W = net.shape
+        self._check_state("refine_igev", net, inp, disp_init, 1)
+        need = pyramid_layout(B * num_groups, H, W, num_levels)[2]
+        if feat_pyr.numel() != need or geo_pyr.numel() != need:
+            raise NndError(f"refine_igev: pyramids hold {feat_pyr.numel()} / {geo_pyr.numel()} floats, expected {need} "
+                           f"for B*G={B * num_groups}, {H}x{W}, {num_levels} levels")
+        if interleaved is not None:
+            _dev(interleaved)
+            need_il = int(lib.nnd_igev_interleaved_floats(B, num_groups, H, W, num_levels))
+            if interleaved.numel() != need_il:
+                raise NndError(f"refine_igev: interleaved copy holds {interleaved.numel()} floats, expected {need_il}")
+        if disp_init is not None:
+            _dev(disp_init)
         n_up = iters if keep_all else 1
         up = torch.empty((n_up, B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
         low = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
@@ -252,8 +281,11 @@ class UpdateBlockEngine:
         d = _dev(fmap1, fmap2, net, inp, self.packed)
         fmap1, fmap2, net, inp = (t.contiguous() for t in (fmap1, fmap2, net, inp))
         B, Cf, H, W = fmap1.shape
-        if fmap2.shape != fmap1.shape or tuple(net.shape[2:]) != (H, W):
+        if fmap2.shape != fmap1.shape or tuple(net.shape[2:]) != (H, W) or net.shape[0] != B:
             raise NndError(f"refine_cre: shapes fmap {tuple(fmap1.shape)} / {tuple(fmap2.shape)}, net {tuple(net.shape)}")
+        self._check_state("refine_cre", net, inp, flow_init, 2)
+        if extra_offset is not None and extra_offset.numel() != B * 18 * H * W:
+            raise NndError(f"refine_cre: extra_offset shape {tuple(extra_offset.shape)} != {(B, 18, H, W)}")
         n_up = iters if keep_all else 1
         up = torch.empty((n_up, B, 2, rate * H, rate * W), dtype=torch.float32, device=d)
         low = torch.empty((B, 2, H, W), dtype=torch.float32, device=d)

@@ -5,12 +5,17 @@ nndepth/models/raft_stereo/configs.py:11-23), `state_dict()` keys and `forward(f
 -> List[{"up_disp": Tensor}]` (nndepth/models/raft_stereo/model.py:17-163), so the reference's
 inference / evaluate scripts can use it unchanged.  Inside `forward()`:
 
-    encoder + cnet_proj      HIP, ONE C-ABI call (csrc/encoder.hip: nnd_encoder_forward; eval-mode BatchNorm folded);
-                             `hip_encoder=False` / training mode / other norms: PyTorch-ROCm        model.py:107-109
+    encoder + cnet_proj      HIP, ONE C-ABI call (csrc/encoder.hip: nnd_encoder_forward; eval-mode BatchNorm folded).
+                             `hip_encoder=False` is the explicit opt-in to PyTorch-ROCm modules for the encoder; there is
+                             no silent fallback: an encoder the HIP path does not build (group norm, dropout) raises
+                                                                                                    model.py:107-109
     corr pyramid build       HIP  (csrc/corr1d.hip)                     model.py:124
     for iters: lookup -> update block -> coords += delta -> convex upsample
                              HIP, ONE C-ABI call for the whole loop     model.py:130-137
                              (csrc/update_block.hip: nnd_raft_stereo_refine)
+
+The classes are inference-only (eval-mode BatchNorm is folded into the convolutions and no autograd graph is recorded):
+`forward()` raises in training mode.
 
 `patch(model)` installs the same kernels behind the three duck-typed seams of an *unmodified*
 reference model instance: `corr_fn`, `update_block`, `convex_upsample`.
@@ -21,6 +26,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import NndError
 from .blocks import BasicUpdateBlock
 from .cost_volume import CorrBlock1D
 from .encoder import BasicEncoder
@@ -36,6 +42,23 @@ def load_weights(model: nn.Module, weights: str, strict_load: bool = True) -> nn
         state = torch.load(weights, map_location="cpu")
     model.load_state_dict(state, strict=strict_load)
     return model
+
+
+def require_eval(model: nn.Module) -> None:
+    """The HIP hot path is inference-only: BatchNorm is folded with its running statistics and nothing records an autograd
+    graph, so a model left in training mode would silently compute something else than the reference's training forward."""
+    if model.training:
+        raise NndError(f"{type(model).__name__} is inference-only on the HIP path: call model.eval() first "
+                       "(training-mode BatchNorm / autograd are not built)")
+
+
+def hip_encoder_blocker(fnet: nn.Module, norms) -> Optional[str]:
+    """Why csrc/encoder.hip cannot run this BasicEncoder, or None."""
+    if fnet.norm_fn not in norms:
+        return f"norm_fn={fnet.norm_fn!r} is not built in HIP (built: {', '.join(norms)})"
+    if fnet.dropout is not None:
+        return "dropout > 0"
+    return None
 
 
 class BaseRAFTStereo(nn.Module):
@@ -79,17 +102,24 @@ class BaseRAFTStereo(nn.Module):
         return self._enc_engine
 
     def forward_fnet(self, frame1, frame2):
-        if (self.hip_encoder and frame1.is_cuda and not self.training and self.fnet.norm_fn in ("batch", "none")
-                and self.fnet.dropout is None):
+        if self.hip_encoder:
+            why = hip_encoder_blocker(self.fnet, ("batch", "none"))
+            if why:
+                raise NndError(f"BaseRAFTStereo: the HIP encoder cannot run this fnet ({why}); pass hip_encoder=False to run "
+                               "the encoder's PyTorch-ROCm modules explicitly")
             # BasicEncoder + cnet_proj in ONE C-ABI call (csrc/encoder.hip); eval-mode BatchNorm folded into the convs
             B = frame1.shape[0]
             fmaps, cnet = self._encoder_engine(frame1.device).forward(torch.cat([frame1, frame2], 0).float(), n_cnet=B)
             return fmaps[:B], fmaps[B:], cnet
-        fmap1, fmap2 = self.fnet([frame1, frame2])
+        fmap1, fmap2 = self.fnet([frame1, frame2])  # explicit opt-in (hip_encoder=False): PyTorch-ROCm modules
         return fmap1, fmap2, self.cnet_proj(fmap1)
 
-    @torch.no_grad()
     def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
+        require_eval(self)
+        with torch.no_grad():
+            return self._forward(frame1, frame2)
+
+    def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
         fmap1, fmap2, cnet = self.forward_fnet(frame1, frame2)
         rate = frame1.shape[-1] // fmap1.shape[-1]
         fmap1, fmap2 = fmap1.float(), fmap2.float()

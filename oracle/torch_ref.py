@@ -224,6 +224,75 @@ def igev_refine(sd: SD, p: str, fp, gp, net, inp, init_disp, iters: int, num_gro
     return ups
 
 
+def _cbr3d(sd: SD, p: str, x: torch.Tensor, stride: int = 1, upsample: bool = False) -> torch.Tensor:
+    """ConvBn3D / Upsampler3D: nndepth/models/igev_stereo/cost_volume.py:101-130 — [trilinear x2, align_corners=True ->]
+    Conv3d(3, bias=False) -> BatchNorm3d (eval) -> LeakyReLU(0.01)."""
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="trilinear", align_corners=True)
+    y = F.conv3d(x, sd[p + ".conv.weight"], None, stride=stride, padding=1)
+    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"], sd[p + ".bn.bias"],
+                     False, 0.0, 1e-5)
+    return F.leaky_relu(y, 0.01)
+
+
+def _feat_gate(sd: SD, p: str, cv: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
+    """FeatureGuidedBlock: igev_stereo/cost_volume.py:133-147 (1x1 conv, BatchNorm2d eval, ReLU, 1x1 conv, sigmoid gate
+    broadcast over the candidate axis)."""
+    a = torch.relu(_bn_eval(sd, p + ".feat_att.1", _conv(sd, p + ".feat_att.0", feat)))
+    return torch.sigmoid(_conv(sd, p + ".feat_att.3", a).unsqueeze(2)) * cv
+
+
+def cost_volume_filter(sd: SD, p: str, x: torch.Tensor, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+    """CostVolumeFilterNetwork.forward: igev_stereo/cost_volume.py:192-210.  x (B,G,W2,H,W1), feats = guide maps at 1/2,
+    1/4, 1/8 of (H,W1) with 40/80/160 channels -> regularised volume, same shape as x."""
+    c1 = _cbr3d(sd, p + ".conv1.1", _cbr3d(sd, p + ".conv1.0", x, 2))
+    c1 = _feat_gate(sd, p + ".conv1_feat_guided", c1, feats[0])
+    c2 = _cbr3d(sd, p + ".conv2.1", _cbr3d(sd, p + ".conv2.0", c1, 2))
+    c2 = _feat_gate(sd, p + ".conv2_feat_guided", c2, feats[1])
+    c3 = _cbr3d(sd, p + ".conv3.1", _cbr3d(sd, p + ".conv3.0", c2, 2))
+    c3 = _feat_gate(sd, p + ".conv3_feat_guided", c3, feats[2])
+    c2 = _cbr3d(sd, p + ".proj_3", torch.cat((_cbr3d(sd, p + ".conv3_up", c3, upsample=True), c2), 1))
+    c2 = _feat_gate(sd, p + ".conv3_up_feat_guided", c2, feats[1])
+    c1 = _cbr3d(sd, p + ".proj_2", torch.cat((_cbr3d(sd, p + ".conv2_up", c2, upsample=True), c1), 1))
+    c1 = _feat_gate(sd, p + ".conv2_up_feat_guided", c1, feats[0])
+    return _cbr3d(sd, p + ".final_conv", _cbr3d(sd, p + ".conv1_up", c1, upsample=True))
+
+
+def cost_volume_filter_spec(p: str, c: int = 8, feat_channels=(40, 80, 160)):
+    """state_dict keys / shapes of CostVolumeFilterNetwork(c, feat_channels), in registration order
+    (igev_stereo/cost_volume.py:150-190)."""
+    spec = []
+
+    def cbr(name, ci, co):
+        spec.append((f"{name}.conv.weight", (co, ci, 3, 3, 3)))
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            spec.append((f"{name}.bn.{k}", (co,)))
+        spec.append((f"{name}.bn.num_batches_tracked", ()))
+
+    def gate(name, cvc, fc):
+        spec.append((f"{name}.feat_att.0.weight", (fc // 2, fc, 1, 1)))
+        spec.append((f"{name}.feat_att.0.bias", (fc // 2,)))
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            spec.append((f"{name}.feat_att.1.{k}", (fc // 2,)))
+        spec.append((f"{name}.feat_att.1.num_batches_tracked", ()))
+        spec.append((f"{name}.feat_att.3.weight", (cvc, fc // 2, 1, 1)))
+        spec.append((f"{name}.feat_att.3.bias", (cvc,)))
+
+    for i, (ci, co) in enumerate(((c, 2 * c), (2 * c, 4 * c), (4 * c, 8 * c)), start=1):
+        cbr(f"{p}.conv{i}.0", ci, co)
+        cbr(f"{p}.conv{i}.1", co, co)
+        gate(f"{p}.conv{i}_feat_guided", co, feat_channels[i - 1])
+    cbr(p + ".conv3_up", 8 * c, 4 * c)
+    cbr(p + ".proj_3", 8 * c, 4 * c)
+    gate(p + ".conv3_up_feat_guided", 4 * c, feat_channels[1])
+    cbr(p + ".conv2_up", 4 * c, 2 * c)
+    cbr(p + ".proj_2", 4 * c, 2 * c)
+    gate(p + ".conv2_up_feat_guided", 2 * c, feat_channels[0])
+    cbr(p + ".conv1_up", 2 * c, c)
+    cbr(p + ".final_conv", c, c)
+    return spec
+
+
 def igev_init_disparity(logits: torch.Tensor) -> torch.Tensor:
     """nndepth/models/igev_stereo/model.py:92-95,145-146: logits (B,D,H,W) = squeezed geometry volume ->
     -sum_d d * softmax_d(logits), (B,1,H,W)."""

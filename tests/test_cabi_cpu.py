@@ -212,3 +212,57 @@ def test_loftr_pack_host(cre_sd):
     with pytest.raises(NndError):
         ops.LoftrEngine(256, 4)  # 64 channels per head: the attention kernels are built for 32
     assert lib.nnd_loftr_layer_forward(256, 8, None, None, None, None, None, 1, 8, 8, None) < 0
+
+
+def test_models_are_inference_only_and_name_their_fallbacks(raft_sd):
+    """No silent PyTorch fallback: training mode raises, an encoder the HIP path does not build raises and
+    names the explicit opt-in, and the refine wrappers validate the shapes the C-ABI cannot see."""
+    from nndepth_amd._lib import NndError
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
+    m = BaseRAFTStereo(iters=1, context_dim=64)
+    x = torch.zeros(1, 3, 32, 64)
+    with pytest.raises(NndError, match="inference-only"):
+        m.train()(x, x)
+    m.eval()
+    m.fnet.norm_fn = "group"
+    with pytest.raises(NndError, match="hip_encoder=False"):
+        m(x, x)
+    reg = CostVolumeFilterNetwork(8, [40, 80, 160])
+    with pytest.raises(NndError, match="inference-only"):
+        reg.train()(torch.zeros(1, 8, 8, 8, 8), [])
+    with pytest.raises(NndError):  # hip = True and a CPU volume: no CPU path exists
+        reg.eval()(torch.zeros(1, 8, 8, 8, 8), [torch.zeros(1, 40, 4, 4), torch.zeros(1, 80, 2, 2), torch.zeros(1, 160, 1, 1)])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nndepth"), reason="needs the reference checkout (build container only)")
+def test_patch_swaps_the_seams_of_the_imported_reference_model(raft_sd):
+    """`patch()` on an UNMODIFIED instance of the reference's BaseRAFTStereo — the three seams are replaced, the
+    update block keeps the reference's state_dict keys (strict load both ways), and the patched seams refuse CPU tensors
+    (nothing computes without the HIP device).  Build container only: the reference never travels to the GPU box."""
+    import sys
+    from oracle.make_golden import _install_standins
+    saved = dict(sys.modules), list(sys.path)
+    try:
+        _install_standins()
+        from nndepth.models.raft_stereo.model import BaseRAFTStereo as RefModel
+        from nndepth_amd._lib import NndError
+        from nndepth_amd.blocks import BasicUpdateBlock
+        from nndepth_amd.cost_volume import CorrBlock1D
+        from nndepth_amd.raft_stereo import patch
+        ref = RefModel(iters=2, context_dim=64).eval()
+        ref.load_state_dict(raft_sd, strict=True)
+        keys = list(ref.state_dict().keys())
+        patch(ref)
+        assert isinstance(ref.update_block, BasicUpdateBlock) and ref.corr_fn is CorrBlock1D
+        assert list(ref.state_dict().keys()) == keys                      # same keys, same order
+        ref.load_state_dict(raft_sd, strict=True)                         # the reference's load_weights path still works
+        assert all(torch.equal(ref.state_dict()[k], raft_sd[k]) for k in keys)
+        with pytest.raises(NndError):                                     # the reference's own forward now reaches our seams
+            ref(torch.zeros(1, 3, 32, 64), torch.zeros(1, 3, 32, 64))
+        with pytest.raises(NndError):
+            ref.convex_upsample(torch.zeros(1, 1, 4, 8), torch.zeros(1, 576, 4, 8), 8)
+    finally:
+        for k in set(sys.modules) - set(saved[0]):
+            del sys.modules[k]
+        sys.path[:] = saved[1]

@@ -308,6 +308,64 @@ def test_batch_consistency(raft_sd):
     assert (both[0] - oa[0]).abs().max() <= 2e-5 and (both[1] - ob[0]).abs().max() <= 2e-5
 
 
+def test_two_host_threads_on_two_streams_equal_serial(raft_sd):
+    """Threading contract of include/nndepth_amd.h: host threads driving distinct streams (and distinct buffers) of one
+    device may call nnd_raft_stereo_refine concurrently — every call owns its fork/join events and its side stream.
+    Two threads x 6 forwards on their own streams must reproduce the serial results bit for bit."""
+    import threading
+    from nndepth_amd import weightgen
+    models = [_model(raft_sd, 6), _model(raft_sd, 6)]  # one engine (workspace) per thread
+    frames = [tuple(f.to(DEV) for f in weightgen.synthetic_frames(20 + i, 1, 96 + 32 * i, 160)) for i in range(2)]
+    serial = [[o["up_disp"].clone() for o in models[i](*frames[i])] for i in range(2)]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                gate.wait()
+                for _ in range(6):
+                    out = models[i](*frames[i])
+                st.synchronize()
+            results[i] = out
+        except Exception as e:  # surfaced below: an exception in a thread must fail the test
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for i in range(2):
+        for k in range(6):
+            assert torch.equal(results[i][k]["up_disp"], serial[i][k]), (i, k)
+
+
+def test_refine_wrappers_validate_shapes(raft_sd):
+    """The refine entry points take raw pointers: the Python layer must reject a pyramid built at another resolution, a
+    hidden state with the wrong channel count or a mis-shaped initial disparity (would be out-of-bounds device accesses)."""
+    from nndepth_amd import ops
+    from nndepth_amd._lib import NndError
+    m = _model(raft_sd, 2)
+    eng = m.update_block.sync_engine(DEV)
+    B, H, W = 1, 12, 24
+    f = torch.randn(B, 256, H, W, device=DEV)
+    pyr = ops.corr1d_build(f, f, 4)
+    net, inp = torch.zeros(B, 128, H, W, device=DEV), torch.zeros(B, 64, H, W, device=DEV)
+    eng.refine(pyr, 4, 4, net, inp, 8, 1)  # the well-formed call works
+    with pytest.raises(NndError, match="pyramid"):
+        eng.refine(ops.corr1d_build(f[..., :16].contiguous(), f[..., :16].contiguous(), 4), 4, 4, net, inp, 8, 1)
+    with pytest.raises(NndError, match="net shape"):
+        eng.refine(pyr, 4, 4, torch.zeros(B, 64, H, W, device=DEV), inp, 8, 1)
+    with pytest.raises(NndError, match="inp shape"):
+        eng.refine(pyr, 4, 4, net, torch.zeros(B, 128, H, W, device=DEV), 8, 1)
+    with pytest.raises(NndError, match="initial"):
+        eng.refine(pyr, 4, 4, net, inp, 8, 1, disp_init=torch.zeros(B, 1, H, W + 1, device=DEV))
+
+
 def test_fused_mask_upsample_matches_unfused(raft_sd, monkeypatch):
     """The fused mask.2+softmax+upsample kernel (mask never written) == mask.2 conv followed by the
     standalone convex_upsample kernel, on the same loop (seam-by-seam path uses the unfused kernels)."""

@@ -123,3 +123,40 @@ def test_prepost_oracle(gold):
         mask = t(g[f"ev_{name}_mask"]) if f"ev_{name}_mask" in g else None
         out = R.eval_criterion(t(g[f"ev_{name}_gt"]), t(g[f"ev_{name}_pred"]), mask, {"kitti-d1": 3.0, "d5": 5.0}, 1000)
         assert [out["epe"], out["kitti-d1"], out["d5"]] == pytest.approx(list(g[f"ev_{name}_out"]), abs=1e-7)
+
+
+@pytest.mark.parametrize("name,hid,ctx,fc,sps", [("convgru_h128_c128", 128, 128, 1, 8), ("convgru_h64_c64_f2", 64, 64, 2, 4)])
+def test_update_block_conv_gru(gold, name, hid, ctx, fc, sps):
+    """a7: ConvGRU (single 3x3 pass, nndepth/blocks/gru.py:40-61) — the oracle's conv_gru and the whole update block with
+    gru="conv_gru" against the imported reference's outputs (oracle/make_golden.py conv_gru)."""
+    from nndepth_amd import weightgen
+    g = gold("update_block_conv_gru.npz")
+    sd = weightgen.fill_state_dict(R.update_block_spec("ub." + name, hid, 36, ctx, fc, sps, gru="conv_gru"))
+    net, inp, corr, flow, x = (t(g[f"{name}_{k}"]) for k in ("net", "inp", "corr", "flow", "gru_x"))
+    with torch.no_grad():
+        h = R.conv_gru(sd, f"ub.{name}.gru", net, x)
+        n, m, d = R.update_block(sd, "ub." + name, net, inp, corr, flow, gru="conv_gru")
+    for got, key in ((h, "gru_out"), (n, "net_out"), (m, "mask_out"), (d, "delta_out")):
+        assert np.abs(got.numpy() - g[f"{name}_{key}"]).max() <= 2e-5, key
+
+
+@pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
+def test_igev_regulariser_oracle(gold, name, B, H, W):
+    """a15: the oracle's CostVolumeFilterNetwork restatement (Conv3d hourglass, BatchNorm3d eval, LeakyReLU, trilinear x2,
+    feature gating) against the reference's regularised volume (igev_volume.npz: geo0), and its key list against the
+    drop-in module's state_dict (which test_igev_model_keys_and_init_disparity ties to the reference's)."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
+    g = gold("igev_volume.npz")
+    spec = R.cost_volume_filter_spec("igev.cv_regularizer")
+    assert [k[len("igev.cv_regularizer."):] for k, _ in spec] == list(CostVolumeFilterNetwork(8, [40, 80, 160]).state_dict().keys())
+    sd = weightgen.fill_state_dict(spec)
+    f1, f2 = t(g[name + "_f1"]), t(g[name + "_f2"])
+    guides = [torch.from_numpy(weightgen.uniform01(f"ig{j}" + name, B * c * (H >> (j + 1)) * (W >> (j + 1))
+                                                   ).reshape(B, c, H >> (j + 1), W >> (j + 1)))
+              for j, c in enumerate((40, 80, 160))]
+    with torch.no_grad():
+        fvol = R.group_corr_volume(f1, f2, 8)
+        geo = R.cost_volume_filter(sd, "igev.cv_regularizer", fvol.permute(0, 1, 4, 2, 3), guides)
+    got = geo.permute(0, 1, 3, 4, 2).reshape(-1, W).numpy()
+    assert np.abs(got - g[name + "_geo0"]).max() <= 2e-6
