@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: stereo pairs/s, RAFT-Stereo base, 544x960, 32 GRU iterations, batch 1 per GPU
-(BASELINE.json configs[1]).  One "step" = one full forward() of one stereo pair per rank: encoder
-(PyTorch-ROCm) + HIP correlation pyramid + the fused HIP refinement loop producing all 32 up_disp maps;
+(BASELINE.json configs[1]).  One "step" = one full forward() of one stereo pair per rank: HIP encoder
+(csrc/encoder.hip) + HIP correlation pyramid + the fused HIP refinement loop producing all 32 up_disp maps;
 at N > 1 every rank works on its own pair (weak scaling, no collective inside forward) and the step ends
 with the RCCL all-gather of the final disparity.  Inputs are resident in HBM before the timed region.
 
@@ -11,7 +11,10 @@ with the RCCL all-gather of the final disparity.  Inputs are resident in HBM bef
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   "roofline":     dominant kernel (fp32-MFMA implicit-GEMM conv) measured live with hipEvents on the
-                  launch stream via the C-ABI's nnd_profile_conv, against the 157.3 TFLOP/s fp32 MFMA peak;
+                  launch stream, against the 157.3 TFLOP/s fp32 MFMA peak: `achieved` is its duration INSIDE the
+                  fused loop (nnd_profile_loop_conv), `standalone` the same launch alone on the chip
+                  (nnd_profile_conv); `hbm_group` = the HBM-bound kernels of the path (pyramid build, lookup,
+                  upsample, IGEV / CREStereo volume kernels) against the 8 TB/s roofline, same run;
   "cpu_baseline": the oracle's PyTorch-eager CPU restatement of the reference forward timed on the
                   host cores (rank 0, N=1 only), and the GPU-vs-oracle max-abs of that same pair.
 """
@@ -26,6 +29,8 @@ sys.path.insert(0, ROOT)
 
 H_IMG, W_IMG, ITERS = 544, 960, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+# algorithmic work of one pair: 32 x 43.15 GFLOP loop + 0.5 GFLOP pyramid + 155.2 GFLOP encoder + cnet_proj
+E2E_TFLOP = (32 * 43.15 + 0.5 + 155.2) / 1e3
 
 
 def usable_cores() -> int:
@@ -47,12 +52,18 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-hbm-group", action="store_true")
+    ap.add_argument("--config", default="raft544", choices=["raft544", "kitti64", "cre8"],
+                    help="raft544 = BASELINE.json configs[1] (the headline, default); kitti64 = configs[3]: 64 KITTI-size pairs "
+                         "sharded over the ranks; cre8 = configs[4]: 8 CREStereo 1080x1920 pairs, 2-stage cascade, sharded")
     args = ap.parse_args()
 
+    if args.config != "raft544":
+        return sharded_config(args)
     import torch
     from nndepth_amd import parallel, weightgen
     from nndepth_amd.raft_stereo import BaseRAFTStereo
@@ -85,14 +96,20 @@ def main():
     torch.cuda.synchronize(dev)
     parallel.barrier()
     torch.cuda.synchronize(dev)
+    # per-step events on the launch stream (no host sync inside the timed region): median next to the mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out, final = step()
+        marks[i + 1].record()
     torch.cuda.synchronize(dev)
     parallel.barrier()
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s (median step {median_ms:.3f} ms)")
 
     result = {
         "metric": "stereo pairs/sec at 544x960, 32 iters (RAFT-Stereo)",
@@ -102,6 +119,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_median": median_ms,
+        "ms_per_step_min_max": [step_ms[0], step_ms[-1]],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -126,15 +145,48 @@ def main():
         # dominant launch = most algorithmic FLOPs (ties -> the first, encoder.convc2: also the longest one inside the loop);
         # picking by measured time would flip between convc2 and flow_head.conv1+mask.0 (same FLOPs, 62 vs 64 us) on noise
         dom = max(rows, key=lambda r: round(r["gflop"], 3))
+        # ... and the same launches where they run in production: inside the fused loop, the flow branch on the side stream
+        from nndepth_amd.cost_volume import CorrBlock1D
+        fmap1, fmap2, cnet = model.forward_fnet(f1, f2)
+        net, inp = torch.split(cnet, [model.hidden_dim, model.context_dim], dim=1)
+        net, inp = torch.tanh(net).contiguous(), torch.relu(inp).contiguous()
+        pyr = CorrBlock1D(fmap1, fmap2, 4, 4)._pyr
+        loop_ms, loop_fl = 0.0, 0.0
+        for i, r in enumerate(rows):
+            if r["conv"] in ("encoder.convc1", "encoder.convf2", "mask.2"):
+                continue  # fused into lookup+convc1 / on the side stream / fused into mask+upsample: no stand-alone launch
+            r["ms_in_loop"] = eng.profile_loop_conv(i, pyr, 4, 4, net, inp, 8, ITERS)
+            r["tflops_in_loop"] = r["gflop"] / r["ms_in_loop"]
+            loop_ms += r["ms_in_loop"]
+            loop_fl += r["gflop"]
         result["roofline"] = {
             "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2) — " + dom["conv"],
-            "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": _traffic(),
-            "launch_ms": dom["ms"], "launch_gflop": dom["gflop"],
+            "achieved": dom["tflops_in_loop"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["tflops_in_loop"] / PEAK_FP32_MFMA_TFLOPS, "traffic": _traffic(),
+            "measured": "inside the fused 32-iteration loop (hipEvents around the launch on its stream, average of iterations 2..32)",
+            "launch_ms": dom["ms_in_loop"], "launch_gflop": dom["gflop"],
+            "standalone": {"launch_ms": dom["ms"], "achieved": dom["tflops"], "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS},
             "all_convs": {"ms_per_iter": tot_ms, "gflop_per_iter": tot_fl / 1e9,
-                          "tflops": tot_fl / tot_ms / 1e9, "frac": tot_fl / tot_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS},
+                          "tflops": tot_fl / tot_ms / 1e9, "frac": tot_fl / tot_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                          "measured": "stand-alone launches"},
+            "loop_convs": {"ms_per_iter": loop_ms, "gflop_per_iter": loop_fl,
+                           "tflops": loop_fl / loop_ms, "frac": loop_fl / loop_ms / PEAK_FP32_MFMA_TFLOPS,
+                           "measured": "the 7 stand-alone conv launches of the recurrence, in the loop"},
+            "end_to_end": {"tflop_per_pair": E2E_TFLOP, "tflops": E2E_TFLOP / (elapsed / args.steps),
+                           "frac": E2E_TFLOP / (elapsed / args.steps) / PEAK_FP32_MFMA_TFLOPS},
             "per_conv": rows,
         }
+        if not args.no_hbm_group:
+            from nndepth_amd import profiling
+            log("roofline: HBM-bound kernels vs 8 TB/s")
+            torch.manual_seed(0)
+            result["roofline"]["hbm_group"] = {
+                "peak_gb_per_s": profiling.HBM_PEAK_GBS,
+                "raft_544x960": profiling.raft_rows(dev),
+                "igev_544x960_per_sample": profiling.igev_rows(dev),
+                "cre_1080x1920": profiling.cre_rows(dev),
+            }
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (oracle port)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
@@ -164,6 +216,85 @@ def main():
     if world > 1:
         import torch.distributed as dist
         parallel.barrier()  # rank 0's roofline leg runs after the timed region: leave together
+        dist.destroy_process_group()
+
+
+def sharded_config(args):
+    """BASELINE.json configs[3] / configs[4]: a fixed batch of pairs sharded over the ranks (strong scaling; one step = one
+    pass over the whole batch; the only collective is the all-gather of the final disparities, nndepth_amd/parallel.py).
+
+      kitti64: 64 pairs of 375x1242 -> Padder(divis_by=32) -> RAFT-Stereo base, 32 iterations, micro-batches of 8 pairs ->
+               unpad -> all-gather of (64,1,375,1242)                          (8 pairs per GPU on a full node)
+      cre8:    8 pairs of 1080x1920 -> CREStereo, 20 iterations, 2-stage cascade (half resolution, then full resolution
+               seeded with it) -> all-gather of (8,2,1080,1920)                (1 pair per GPU on a full node)
+    """
+    import torch
+    from nndepth_amd import parallel, weightgen
+
+    rank, world, local = parallel.init_distributed("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if args.config == "kitti64":
+        from nndepth_amd.prepost import Padder
+        from nndepth_amd.raft_stereo import BaseRAFTStereo
+        n_pairs, micro, hw = 64, 8, (375, 1242)
+        model = BaseRAFTStereo(iters=ITERS, context_dim=64)
+        weightgen.fill_module_(model)
+        model = model.to(dev).eval()
+        padder = Padder(hw, divis_by=32)
+
+        def forward(f1, f2):
+            p1, p2 = padder.pad(f1, f2)
+            return padder.unpad(model(p1, p2)[-1]["up_disp"])
+        name = "RAFT-Stereo base (ctx 64), 64 x 375x1242 (Padder 32 -> 384x1248), 32 iters, micro-batches of 8"
+        metric = "stereo pairs/sec at KITTI 1242x375, 32 iters (RAFT-Stereo), batch 64 sharded"
+    else:
+        from nndepth_amd.cre_stereo import CREStereoBase, two_stage_forward
+        n_pairs, micro, hw = 8, 1, (1080, 1920)
+        model = CREStereoBase(iters=20)
+        weightgen.fill_module_(model)
+        model = model.to(dev).eval()
+
+        def forward(f1, f2):
+            return two_stage_forward(model, f1, f2)[-1]["up_disp"]
+        name = "CREStereo, 8 x 1080x1920, 20 iters, 2-stage cascade (half resolution, then full resolution seeded with it)"
+        metric = "stereo pairs/sec at 1080x1920, 20 iters (CREStereo 2-stage), batch 8 sharded"
+    assert world <= n_pairs
+    # the rank's pairs resident in HBM before the timed region (synthetic, a different pair per id)
+    mine = list(parallel.shard_range(n_pairs, rank, world))
+    cache = {i: tuple(t.to(dev) for t in weightgen.synthetic_frames(200 + i, 1, *hw)) for i in mine}
+
+    def load(ids):
+        return torch.cat([cache[i][0] for i in ids]), torch.cat([cache[i][1] for i in ids])
+
+    def step():
+        return parallel.sharded_inference(n_pairs, load, forward, micro, rank, world)
+
+    log(f"rank {rank}/{world}: {len(mine)} of {n_pairs} pairs resident on {dev}; warm-up x{args.warmup}")
+    for _ in range(args.warmup):
+        step()
+        torch.cuda.synchronize(dev)
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape[0] == n_pairs and tuple(out.shape[2:]) == hw
+    if rank == 0:
+        print(json.dumps({
+            "metric": metric, "value": n_pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "pairs_per_step": n_pairs, "pairs_per_rank": len(mine),
+                       "parallelism": f"batch shards x{world} + RCCL all-gather of the disparities"}}))
+    if world > 1:
+        import torch.distributed as dist
+        parallel.barrier()
         dist.destroy_process_group()
 
 

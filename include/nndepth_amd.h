@@ -333,6 +333,15 @@ int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed
 int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed_dev, float* workspace,
                      int B, int H, int W, int which, int reps, void* stream,
                      float* ms_out, double* flops_out);
+/* The same conv timed where it runs in production: inside the fused RAFT-Stereo loop (arguments as
+ * nnd_raft_stereo_refine, only the last up_disp is kept), bracketed by hipEvents on `stream` in every iteration while the
+ * flow branch shares the chip from the side stream.  *ms_out = average over iterations 2..iters (event-to-event, so it
+ * includes the launch gap in front of the kernel).  Synchronises `stream`.  `which` must be one of the stand-alone
+ * launches of the recurrence (not convc1 / convf2 / mask.2, which are fused or on the side stream).                    */
+int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed_dev, const float* pyramid,
+                          int num_levels, int radius, const float* net, const float* inp, float* up_out,
+                          float* workspace, int B, int H, int W, int rate, int iters, int which, void* stream,
+                          float* ms_out);
 /* Diagnostic: sustained fp32-MFMA rate of this device (dependent v_mfma_f32_32x32x2 chains, no memory
  * traffic) at `waves_per_simd` resident waves; `scratch_dev` is any device buffer of >= 1 float.        */
 int nnd_profile_mfma_peak(int waves_per_simd, int iters, void* stream, float* scratch_dev, float* tflops_out);

@@ -94,6 +94,8 @@ SIGNATURES = {
     "nnd_volume_gate": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_profile_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(C.c_float),
                               C.POINTER(C.c_double)]),
+    "nnd_profile_loop_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P,
+                                   C.POINTER(C.c_float)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),
     "nnd_num_convs": (_I, [C.POINTER(UpdateBlockDesc)]),
     "nnd_conv_name": (C.c_char_p, [C.POINTER(UpdateBlockDesc), _I]),

@@ -648,6 +648,21 @@ struct CreArgs {
     int C;
 };
 
+// Profiling hook of nnd_profile_loop_conv: when set (thread-local, so only the calling thread's loops are affected), every
+// iteration of the fused loop brackets conv `which` on the caller's stream with a pair of timing events.
+struct LoopProbe {
+    int which;
+    std::vector<hipEvent_t> ev;  // 2 per iteration
+};
+static thread_local LoopProbe* t_probe = nullptr;
+static void probe_mark(int id, hipStream_t s) {
+    if (!t_probe || t_probe->which != id) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    t_probe->ev.push_back(e);
+}
+
 // geo_pyramid != nullptr selects the IGEV variant: combined two-volume lookup over `groups` groups and
 // absolute coordinates into the update block / upsample (igev_stereo/model.py:152-158).  cre != nullptr selects the
 // CREStereo variant (then pyramid is unused and disp_init is the initial 2-channel flow, NCHW, or null for zero).
@@ -724,6 +739,13 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     const bool fused_lk = !cre && !no_fuse_lk;
+    // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
+    auto loop_conv = [&](int id) -> int {
+        probe_mark(id, s);
+        const int rc_ = run_conv(p, packed, w, id, c, nullptr, nullptr, B, H, W, s);
+        probe_mark(id, s);
+        return rc_;
+    };
     NND_HIP_CHECK(hipEventRecord(st->adv, s));
     st->forked = true;
     for (int it = 0; it < iters; ++it) {
@@ -741,16 +763,16 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(lookup(s, it));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
         }
-        NND_TRY(run_conv(p, packed, w, C_C2, c, nullptr, nullptr, B, H, W, s));
+        NND_TRY(loop_conv(C_C2));
         NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
-        NND_TRY(run_conv(p, packed, w, C_CV, c, nullptr, nullptr, B, H, W, s));
-        NND_TRY(run_conv(p, packed, w, C_ZR1X, c, nullptr, nullptr, B, H, W, s));
-        NND_TRY(run_conv(p, packed, w, C_Q1X, c, nullptr, nullptr, B, H, W, s));
+        NND_TRY(loop_conv(C_CV));
+        NND_TRY(loop_conv(C_ZR1X));
+        NND_TRY(loop_conv(C_Q1X));
         if (p.sep) {
-            NND_TRY(run_conv(p, packed, w, C_ZR2X, c, nullptr, nullptr, B, H, W, s));
-            NND_TRY(run_conv(p, packed, w, C_Q2X, c, nullptr, nullptr, B, H, W, s));
+            NND_TRY(loop_conv(C_ZR2X));
+            NND_TRY(loop_conv(C_Q2X));
         }
-        NND_TRY(run_conv(p, packed, w, C_FHM, c, nullptr, nullptr, B, H, W, s));  // flow_head.conv1 and mask.0 in one launch
+        NND_TRY(loop_conv(C_FHM));  // flow_head.conv1 and mask.0 in one launch
         NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
         NND_HIP_CHECK(hipEventRecord(st->adv, s));  // the flow is final: stream A may start the next flow branch
         float* up_it = up_out + (int64_t)it * up_iter_stride;
@@ -895,6 +917,35 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, flo
     (void)hipEventDestroy(e1);
     return rc;
 }
+}
+
+extern "C" int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
+                                     int radius, const float* net, const float* inp, float* up_out, float* workspace, int B, int H,
+                                     int W, int rate, int iters, int which, void* stream, float* ms_out) {
+    NND_REQUIRE(ms_out && which >= 0 && which < C_LOOP_COUNT && which != C_C1 && which != C_F2 && which != C_M2 && iters > 0,
+                "profile_loop_conv: conv %d is not a stand-alone launch of the recurrence", which);
+    LoopProbe probe;
+    probe.which = which;
+    t_probe = &probe;
+    int rc = enqueue_refine(desc, packed, pyramid, num_levels, radius, net, inp, nullptr, up_out, 0, nullptr, nullptr, workspace, B,
+                            H, W, rate, iters, stream);
+    t_probe = nullptr;
+    if (rc == NND_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = NND_ERR_HIP;
+    double sum = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < probe.ev.size(); i += 2) {
+        float ms = 0.f;
+        // the first iteration starts behind the per-pair prologue: leave it out of the average
+        if (rc == NND_OK && i >= 2 && hipEventElapsedTime(&ms, probe.ev[i], probe.ev[i + 1]) == hipSuccess) {
+            sum += ms;
+            ++n;
+        }
+    }
+    for (hipEvent_t e : probe.ev) (void)hipEventDestroy(e);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(n > 0, "profile_loop_conv: needs at least 2 iterations");
+    *ms_out = (float)(sum / n);
+    return NND_OK;
 }
 
 // ------------------------------------------------------------------------------ MFMA peak probe

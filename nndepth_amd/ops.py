@@ -325,6 +325,23 @@ class UpdateBlockEngine:
         return ms.value, fl.value
 
 
+    def profile_loop_conv(self, which: int, pyr, num_levels: int, radius: int, net, inp, rate: int, iters: int) -> float:
+        """-> avg ms of conv `which` INSIDE the fused RAFT-Stereo loop (hipEvents on the launch stream in every iteration,
+        the flow branch sharing the chip from the side stream as in production)."""
+        d = _dev(pyr, net, inp, self.packed)
+        net, inp = net.contiguous(), inp.contiguous()
+        B, _, H, W = net.shape
+        self._check_state("profile_loop_conv", net, inp, None, 1)
+        up = torch.empty((B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
+        ws = self.workspace(B, H, W, d)
+        ms = C.c_float()
+        with torch.cuda.device(d):
+            check(lib.nnd_profile_loop_conv(C.byref(self.desc), _p(self.packed), _p(pyr), num_levels, radius, _p(net), _p(inp),
+                                            _p(up), _p(ws), B, H, W, rate, iters, which, _stream(d), C.byref(ms)),
+                  "profile_loop_conv")
+        return ms.value
+
+
 # ------------------------------------------------------------------ IGEV geometry-encoding volume
 def group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, group_channels: int,
                      num_levels: int) -> torch.Tensor:

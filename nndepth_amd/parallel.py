@@ -44,6 +44,52 @@ def gather_disparity(local: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_ragged(local: torch.Tensor, n_items: int) -> torch.Tensor:
+    """All-gather of per-rank batches whose sizes follow shard_range(n_items, rank, world) (they differ by at most one):
+    every rank pads its slice to the largest shard, ONE all_gather_into_tensor, then the padding rows are dropped.
+    -> (n_items, ...) in item order, on every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert local.shape[0] == n_items
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = [len(shard_range(n_items, r, world)) for r in range(world)]
+    assert local.shape[0] == counts[rank], f"rank {rank} holds {local.shape[0]} items, its shard has {counts[rank]}"
+    cap = max(counts)
+    if local.shape[0] < cap:
+        pad = torch.zeros((cap - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((world * cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    if all(c == cap for c in counts):
+        return out
+    return torch.cat([out[r * cap:r * cap + counts[r]] for r in range(world)], 0)
+
+
+def sharded_inference(n_pairs: int, load_pairs, forward_fn, micro_batch: int, rank: int = None, world: int = None,
+                      gather: bool = True) -> torch.Tensor:
+    """The batch-parallel job of BASELINE.json configs[3] / [4] (north_star: "full-image batches shard over the 8 GPUs of
+    one node with RCCL all-gather of disparity only for the batch-parallel case"):
+
+        pairs shard_range(n_pairs, rank, world)  ->  micro-batches of `micro_batch` pairs
+        load_pairs(list of pair ids) -> (frame1, frame2) resident on this rank's GPU
+        forward_fn(frame1, frame2)   -> final disparity (b, C, H, W) of the micro-batch      [no collective inside]
+        one all-gather of the rank's disparities at the end -> (n_pairs, C, H, W) in pair order on every rank.
+
+    With gather=False the rank-local result is returned (what a caller that only needs its own pairs would use)."""
+    if rank is None or world is None:
+        r, w, _ = env_world()
+        rank, world = (r, w) if rank is None else (rank, world)
+    mine = list(shard_range(n_pairs, rank, world))
+    outs = []
+    for i in range(0, len(mine), micro_batch):
+        ids = mine[i:i + micro_batch]
+        f1, f2 = load_pairs(ids)
+        outs.append(forward_fn(f1, f2))
+    assert outs, f"rank {rank} of {world} owns no pair of {n_pairs}: run with world <= n_pairs"
+    local = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+    return gather_ragged(local, n_pairs) if gather else local
+
+
 def max_over_ranks(seconds: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds

@@ -53,8 +53,53 @@ def test_shard_and_gather_world2():
     assert res[0][3] == res[1][3] == 2.0  # max over ranks
 
 
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nndepth_amd import parallel
+    parallel.init_distributed("gloo")
+    seen = []
+
+    def load(ids):  # stands in for "decode + upload + Padder": frames that carry their pair id
+        seen.append(list(ids))
+        f = torch.tensor(ids, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 3, 4, 6).contiguous()
+        return f, f + 0.5
+
+    def forward(f1, f2):  # stub model: "disparity" = pair id + 0.5 at 1 channel
+        return (f1[:, :1] + f2[:, :1]) * 0.5 + 0.25
+
+    out = parallel.sharded_inference(5, load, forward, micro_batch=2)  # 5 pairs over 2 ranks: 3 (2 + 1) and 2
+    local = parallel.sharded_inference(5, load, forward, micro_batch=2, gather=False)
+    parallel.barrier()
+    q.put((rank, seen[:len(seen) // 2], out[:, 0, 0, 0].tolist(), tuple(out.shape), local[:, 0, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_inference_world2():
+    """Control flow of bench.py --config kitti64 / cre8 (nndepth_amd.parallel.sharded_inference) with a stub model on gloo:
+    contiguous shards, micro-batches, ragged all-gather back into pair order on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [[0, 1], [2]] and res[1][1] == [[3, 4]]          # micro-batches of the two shards
+    want = [0.5, 1.5, 2.5, 3.5, 4.5]
+    assert res[0][2] == res[1][2] == want and res[0][3] == (5, 1, 4, 6)   # pair order, on every rank
+    assert res[0][4] == want[:3] and res[1][4] == want[3:]
+
+
 def test_single_process_is_a_noop():
     from nndepth_amd import parallel
     x = torch.arange(6.0).view(1, 1, 2, 3)
     assert parallel.gather_disparity(x) is x
     assert parallel.max_over_ranks(3.5, "cpu") == 3.5
+    y = torch.arange(3.0).view(3, 1, 1, 1)
+    assert parallel.gather_ragged(y, 3) is y
+    got = parallel.sharded_inference(3, lambda ids: (y[ids], y[ids]), lambda a, b: a + b, micro_batch=2, rank=0, world=1)
+    assert got[:, 0, 0, 0].tolist() == [0.0, 2.0, 4.0]
