@@ -615,6 +615,21 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     NND_REQUIRE((long)(L.Cin + 2 * L.CI_T) * tiled_plane(Hin, Win) < (1L << 31), "conv: plane offsets exceed 32 bits");
     TileCfg cfg;
     NND_REQUIRE(pick_tile(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv: no tile configuration for %dx%d Cin=%d", L.KH, L.KW, L.Cin);
+    {   // LDS sizing rule, re-derived independently of pick_tile (DESIGN.md §4 "staging bounds"): two patch buffers of
+        // ks*CI_T channels + the spare word that swallows the stores of non-staging threads, and — aliasing them after the
+        // last barrier — one 32x32 partial tile per wave for the split-K exchange; every staging thread needs a slot.
+        const int SR_ = 32 / NND_SC, st = L.stride;
+        const int PR_ = (SR_ - 1) * st + L.KH, PC_ = (cfg.P * NND_SC - 1) * st + L.KW;
+        const size_t patch = (size_t)st * st * ((PR_ + st - 1) / st) * patch_stride((PC_ + st - 1) / st, NND_SC);
+        NND_REQUIRE(cfg.lds >= ((size_t)2 * cfg.ks * L.CI_T * patch + 1) * sizeof(float) &&
+                        (cfg.ks == 1 || cfg.lds >= (size_t)cfg.wco * cfg.ks * cfg.P * 1024 * sizeof(float)) &&
+                        cfg.lds <= 160 * 1024,
+                    "conv: LDS plan %zu B does not cover the patch buffers / split-K tiles", cfg.lds);
+        NND_REQUIRE(cfg.npos == PR_ * PC_ && cfg.npos * cfg.ngroups <= 64 * cfg.wco * cfg.ks &&
+                        cfg.ngroups * cfg.ne >= cfg.ks * L.CI_T && cfg.ne <= 16,
+                    "conv: staging plan (%d positions x %d groups x %d) does not cover %d channels", cfg.npos, cfg.ngroups,
+                    cfg.ne, cfg.ks * L.CI_T);
+    }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src0 = io.src0.ptr; a.bs0 = io.src0.bstride; a.c0 = io.src0.C;

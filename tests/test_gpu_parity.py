@@ -409,6 +409,29 @@ def test_conv2d_generic_shapes():
             assert (y - exp).abs().max() <= 2e-5, (Cout, Cin, KH, KW, B, H, W, relu)
 
 
+def test_conv_staging_never_reads_outside_the_image():
+    """Regression for the round-1 GPU fault ("staging bounds"; gpurun_out/test2.log, dbg3-5.log): with >= 128
+    input channels left in a K chunk the first conv kernel let masked staging slots (halo positions outside the image,
+    slots past the end of the patch) issue real global loads — wrong halo values at best, a memory access fault at
+    worst.  Shapes of that trail: Cin >= 128 with 3x3 / 1x5 / 1x1 (+ Cin 512), a ragged 12x20 image of 4x8 tiles, a
+    single 4x8 tile, and a split-K (ks = 2) configuration.  The input is a window of a larger buffer poisoned with 1e6:
+    any read outside the image shows as a huge error."""
+    from nndepth_amd import ops
+    torch.manual_seed(7)
+    for (Cout, Cin, KH, KW, B, H, W) in [(32, 128, 3, 3, 1, 12, 20), (64, 128, 3, 3, 1, 12, 20), (32, 128, 1, 5, 1, 12, 20),
+                                         (32, 128, 1, 1, 1, 12, 20), (32, 512, 1, 1, 1, 12, 20), (32, 128, 3, 3, 1, 4, 8),
+                                         (256, 256, 1, 5, 1, 68, 120), (128, 320, 5, 1, 2, 9, 11)]:
+        w = torch.randn(Cout, Cin, KH, KW) / (Cin * KH * KW) ** 0.5
+        b = torch.randn(Cout)
+        x = torch.randn(B, Cin, H, W)
+        big = torch.full((3, x.numel()), 1e6, device=DEV)
+        big[1] = x.reshape(-1).to(DEV)
+        xd = big[1].view(B, Cin, H, W)
+        ref = torch.nn.functional.conv2d(x, w, b, padding=(KH // 2, KW // 2))
+        y = ops.Conv2d(w, b)(xd).cpu()
+        assert (y - ref).abs().max() <= 2e-5, (Cout, Cin, KH, KW, B, H, W, float((y - ref).abs().max()))
+
+
 # ------------------------------------------------------------ IGEV geometry-encoding volume (a12-a14)
 @pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
 def test_igev_volume_golden(ops, gold, name, B, H, W):
