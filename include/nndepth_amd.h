@@ -22,7 +22,8 @@
  *     un-ordered behind `stream`;
  *   - diagnostic environment switches (read per call; they select between kernels that the parity tests prove
  *     equivalent, never a non-HIP path): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
- *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
+ *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
+ *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
  *     (synchronise and name every launch of the update block on stderr).
@@ -144,6 +145,12 @@ typedef struct {
     int32_t flow_channels; /* 1 (RAFT/IGEV) or 2 (CRE) */
     int32_t mask_channels; /* 9*rate*rate: 576 (/8) or 144 (/4) */
     int32_t gru_kind;      /* 0 = "sep_conv" (1x5 then 5x1), 1 = "conv_gru" (3x3) */
+    int32_t arithmetic;    /* MFMA convolutions of the update block, except convc1 and mask.2 (fused with the lookup / the
+                              upsample: always fp32):
+                              0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, an fp32 fmaf chain) — the default;
+                              3 = fp32 operands carried as 3 bf16 pieces each, the 6 products x_i*w_j with i+j <= 2
+                                  on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/conv_split.hip): same result
+                                  to fp32 rounding level (dropped terms <= 2^-24 |x||w|), 0.375x the matrix time.            */
 } nnd_update_block_desc;
 
 /* Number of weight/bias tensors expected by nnd_update_block_pack, in the order of the
@@ -180,6 +187,14 @@ int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin,
                     float* packed_host);
 int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
                        int Cout, int KH, int KW, int relu, void* stream);
+/* The same with the arithmetic chosen (see nnd_update_block_desc.arithmetic): 0 = exact fp32 MFMA (identical to the
+ * functions above), 3 = fp32 operands as 3 bf16 pieces on the bf16 MFMA (csrc/conv_split.hip; needs Cin % 16 == 0).
+ * The packed blob is specific to the arithmetic it was packed for.                                                  */
+int64_t nnd_conv2d_packed_floats_ex(int Cout, int Cin, int KH, int KW, int arithmetic);
+int nnd_conv2d_pack_ex(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW, int arithmetic,
+                       float* packed_host);
+int nnd_conv2d_forward_ex(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
+                          int Cout, int KH, int KW, int relu, int arithmetic, void* stream);
 
 /* Convolution + folded eval-mode BatchNorm + ReLU / residual epilogue (the building block of the encoder):
  *   y = conv(x; w, stride, "same" padding K/2) ; y = (y + bias - mean) * gamma / sqrt(var + eps) + beta   [norm optional]

@@ -16,7 +16,8 @@ class NndError(RuntimeError):
 
 class UpdateBlockDesc(C.Structure):
     _fields_ = [("hidden_dim", C.c_int32), ("context_dim", C.c_int32), ("cor_planes", C.c_int32),
-                ("flow_channels", C.c_int32), ("mask_channels", C.c_int32), ("gru_kind", C.c_int32)]
+                ("flow_channels", C.c_int32), ("mask_channels", C.c_int32), ("gru_kind", C.c_int32),
+                ("arithmetic", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -58,6 +59,9 @@ SIGNATURES = {
     "nnd_conv2d_packed_floats": (C.c_int64, [_I, _I, _I, _I]),
     "nnd_conv2d_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "nnd_conv2d_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_conv2d_packed_floats_ex": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "nnd_conv2d_pack_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_conv2d_forward_ex": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_mask_upsample_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_raft_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),

@@ -20,7 +20,7 @@ def _conv(ci, co, k, pad):
 
 class BasicUpdateBlock(nn.Module):
     def __init__(self, hidden_dim: int, cor_planes: int, context_dim: int = 128, gru: str = "sep_conv",
-                 flow_channel: int = 2, spatial_scale: Union[Tuple[int, int], int] = 8):
+                 flow_channel: int = 2, spatial_scale: Union[Tuple[int, int], int] = 8, arithmetic: str = "fp32"):
         super().__init__()
         sps = spatial_scale ** 2 if isinstance(spatial_scale, int) else spatial_scale[0] * spatial_scale[1]
         gin = hidden_dim + context_dim + hidden_dim
@@ -49,7 +49,8 @@ class BasicUpdateBlock(nn.Module):
         self.flow_head = fh
         self.mask = nn.Sequential(_conv(hidden_dim, hidden_dim * 2, 3, 1), nn.ReLU(inplace=True),
                                   _conv(hidden_dim * 2, sps * 9, 1, 0))
-        self.engine = ops.UpdateBlockEngine(hidden_dim, context_dim, cor_planes, flow_channel, sps * 9, gru)
+        # arithmetic of the fused loops' convolutions: "fp32" (exact fp32 MFMA, default) or "bf16x3" (csrc/conv_split.hip)
+        self.engine = ops.UpdateBlockEngine(hidden_dim, context_dim, cor_planes, flow_channel, sps * 9, gru, arithmetic)
         self._packed_version = None
 
     def _version(self):

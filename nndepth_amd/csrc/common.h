@@ -56,11 +56,16 @@ enum ConvEpilogue {
 struct ConvLayer {
     int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (32, 128 for wide 1x1, 16 for stride 2)
     int stride = 1;               // 1 or 2 ("same" padding K/2; output = ceil(input / stride) for odd K)
+    int arith = 0;                // 0: exact fp32 MFMA (conv_mfma.hip); 3: fp32 carried as 3 bf16 pieces on the bf16 MFMA
+                                  //    (conv_split.hip; CI_T = 16, weights packed as bf16 fragments)
     int64_t s_off = -1;           // float offset of the per-channel scale (EPI_AFFINE), ncb*32 floats; -1: none
     int nchunks;                  // ceil(Cin / CI_T)
     int ncb;                      // ceil(Cout / 32) output-channel blocks
     int64_t w_off, b_off;         // float offsets in the blob
-    int64_t w_floats() const { return (int64_t)ncb * nchunks * KH * KW * CI_T * 32; }
+    int64_t w_floats() const {
+        return arith ? (int64_t)ncb * nchunks * KH * KW * arith * 256  // [cb][chunk][tap][piece] x 64 lanes x 16 B
+                     : (int64_t)ncb * nchunks * KH * KW * CI_T * 32;
+    }
     int64_t b_floats() const { return (int64_t)ncb * 32; }
     double flops(int B, int H, int W) const { return 2.0 * B * H * W * (double)Cout * Cin * KH * KW; }
 };
@@ -95,6 +100,13 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
 // w[i]: (cout[i], Cin, KH, KW) row-major, b[i]: (cout[i]).
 void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const float* const* b,
                const int* cout, float* blob, const int* ci_map = nullptr, int cin_src = 0);
+
+// conv_split.hip: the same convolution with fp32 operands carried as split bf16 pieces on the 16-bit MFMA (L.arith != 0);
+// launch_conv / pack_conv dispatch to these.
+bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith);
+int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W, hipStream_t stream);
+void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, const float* const* b, const int* cout, float* blob,
+                     const int* ci_map, int cin_src);
 
 // corr1d.hip
 // `tiled`: coords / sampled features (resp. flow / mask) are tile-major workspace tensors (layout.h), else NCHW

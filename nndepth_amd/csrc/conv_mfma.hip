@@ -24,6 +24,7 @@
 // Replaces the nn.Conv2d calls of nndepth/blocks/update_block.py:57-65,26-36,97-112 and
 // nndepth/blocks/gru.py:22-37,53-61 (reference files; semantics restated in oracle/torch_ref.py).
 #include "common.h"
+#include "conv_epilogue.h"
 #include "layout.h"
 
 #include <cmath>
@@ -32,8 +33,6 @@
 #include <type_traits>
 
 namespace nnd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef NND_INTERLEAVE
 #define NND_INTERLEAVE 0
@@ -63,56 +62,6 @@ __device__ unsigned long long g_stamps[4096 * 8];
 #define NND_STAMP(i)
 #endif
 
-struct ConvArgs {
-    const float* src0;
-    const float* src1;
-    long bs0, bs1;
-    int c0, c1;
-    const float* wpk;
-    const float* bias;
-    float* out0;
-    float* out1;
-    long obs0, obs1;
-    const float* aux0;
-    const float* aux1;
-    long abs0, abs1;
-    const float* bmap;  // optional per-pixel bias (B, Cout, H, W) added instead of bias[co]
-    long bmbs;
-    Lay ls, ld;         // layout of the sources / of every destination-side tensor (out*, aux*, bmap)
-    int H, W, Cout, nchunks, epi, hidden;  // H, W: OUTPUT size
-    int Hin, Win;                          // input size (== H, W for stride 1)
-    int tiles_x, wco, ks, npos, ngroups;
-    int flags;                             // EPI_AFFINE: bit 0 ReLU after the affine, bit 1 ReLU after the residual add,
-                                           // bit 2 LeakyReLU (negative slope = scale) after the affine
-    const float* cscale;                   // EPI_AFFINE: per-channel scale (folded norm), shift comes in through `bias`
-    float scale;
-};
-
-// exp(x) to ~1 ulp without libm's special-case branches: x*log2(e) is split into the rounded product t and its
-// exact residual r (fma), so exp(x) = exp2(t) * 2^r ~= exp2(t) * (1 + r*ln2); v_exp_f32 itself is ~1 ulp.
-__device__ __forceinline__ float exp_acc(float x) {
-    const float L2E = 1.44269504088896341f;
-    x = fminf(fmaxf(x, -87.0f), 88.0f);
-    const float t = x * L2E;
-    const float r = fmaf(x, L2E, -t) + x * 1.92596299e-8f;  // + x * (log2e - (float)log2e)
-    const float e = __builtin_amdgcn_exp2f(t);
-    return fmaf(e, r * 0.693147180559945f, e);
-}
-// 1/d with one Newton step on v_rcp_f32 (<= 1 ulp)
-__device__ __forceinline__ float rcp_acc(float d) {
-    float y = __builtin_amdgcn_rcpf(d);
-    return fmaf(fmaf(-d, y, 1.0f), y, y);
-}
-__device__ __forceinline__ float sigmoidf_(float v) { return rcp_acc(1.0f + exp_acc(-v)); }
-// tanh(x) = sign(x) * (1 - 2/(exp(2|x|) + 1)); for |x| < 0.04 the odd series avoids the cancellation
-__device__ __forceinline__ float tanhf_(float v) {
-    const float ax = fabsf(v);
-    const float big = 1.0f - 2.0f * rcp_acc(exp_acc(2.0f * ax) + 1.0f);
-    const float x2 = ax * ax;
-    const float small = ax * fmaf(x2, fmaf(x2, 0.133333333f, -0.333333333f), 1.0f);
-    return copysignf(ax < 0.04f ? small : big, v);
-}
-
 // NE: patch elements staged per thread per super-chunk (the thread owns one patch position and NE channels)
 template <int KH, int KW, int CI_T, int P, int NE, int STR = 1>
 __global__ void __launch_bounds__((P == 1 ? 768 : 512)) __attribute__((amdgpu_waves_per_eu((P == 1 && NE == 8 ? 4 : 1))))
@@ -139,8 +88,8 @@ conv_mfma_kernel(ConvArgs a) {
     const int cb = blockIdx.y * wco + cbi;
     const bool active = cb * 32 < a.Cout;  // trailing waves of the last workgroup only help staging
     const int b = blockIdx.z;
-    const int H = a.H, W = a.W, Hin = a.Hin, Win = a.Win;
-    const long SP = a.ls.plane, DP = a.ld.plane;  // channel strides of the source / destination tensors
+    const int Hin = a.Hin, Win = a.Win;
+    const long SP = a.ls.plane;  // channel stride of the source tensors
     // LDS patch geometry is compile-time so every B-operand read is base + immediate offset.
     // Row stride S is an odd multiple of SC: lanes (r, c) then hit 32 distinct banks.
     // Stride 2: the input patch is stored split into its 4 (row, col) parity phases, so that the operand of tap
@@ -344,87 +293,14 @@ conv_mfma_kernel(ConvArgs a) {
     }
 
     NND_STAMP(3);
-    // ---- epilogue: lane holds pixel (y, x_pp) and 16 output channels.  All loads (bias, h, z) are issued
-    // before any store: out0 may alias aux0 (GRU blend in place), which would otherwise serialise load/store.
-    const int y = ty0 + r;
-    const int epi = a.epi;
-    float bias_r[16];
+    {   // ---- epilogue (conv_epilogue.h): lane holds pixel (y, x_pp) and 16 output channels
+        int ys[P], xs[P];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-        bias_r[reg] = (!a.bmap && reg >= reg0 && reg < reg0 + nreg && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int pp = 0; pp < P; ++pp) {
-        const int x = tx0 + pp * SC + c;
-        const bool pix_ok = (y < H && x < W);
-        const long pix = pix_ok ? pix_off(a.ld, y, x) : 0;
-        float h_r[16], z_r[16];
-        if (a.bmap) {  // precomputed context term of the GRU convs (constant over the iterations of a pair)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
-                bias_r[reg] = ok ? a.bmap[b * a.bmbs + co * DP + pix] : 0.f;
-            }
+        for (int pp = 0; pp < P; ++pp) {
+            ys[pp] = ty0 + r;
+            xs[pp] = tx0 + pp * SC + c;
         }
-        if (epi == EPI_AFFINE) {  // z_r <- per-channel scale, h_r <- residual (dst layout), bias_r = shift
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
-                z_r[reg] = ok ? a.cscale[co] : 0.f;
-                h_r[reg] = (ok && a.aux0) ? a.aux0[b * a.abs0 + co * DP + pix] : 0.f;
-            }
-        }
-        if (epi == EPI_GRU_ZR || epi == EPI_GRU_Q) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-                const bool ok = pix_ok && reg >= reg0 && reg < reg0 + nreg && co < a.Cout;
-                h_r[reg] = 0.f;
-                z_r[reg] = 0.f;
-                if (epi == EPI_GRU_Q) {
-                    if (ok) {
-                        h_r[reg] = a.aux0[b * a.abs0 + co * DP + pix];
-                        z_r[reg] = a.aux1[b * a.abs1 + co * DP + pix];
-                    }
-                } else if (ok && co >= a.hidden) {
-                    h_r[reg] = a.aux0[b * a.abs0 + (co - a.hidden) * DP + pix];
-                }
-            }
-        }
-        if (!pix_ok) continue;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            if (reg < reg0 || reg >= reg0 + nreg) continue;
-            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-            if (co >= a.Cout) continue;
-            const float v = acc[pp][reg] + bias_r[reg];
-            if (epi == EPI_RELU) {
-                a.out0[b * a.obs0 + co * DP + pix] = fmaxf(v, 0.f);
-            } else if (epi == EPI_LINEAR) {
-                a.out0[b * a.obs0 + co * DP + pix] = v;
-            } else if (epi == EPI_SCALE) {
-                a.out0[b * a.obs0 + co * DP + pix] = a.scale * v;
-            } else if (epi == EPI_AFFINE) {  // folded norm: y = acc*scale + shift; optional ReLU, residual add, ReLU
-                float y2 = fmaf(acc[pp][reg], z_r[reg], bias_r[reg]);
-                if (a.flags & 4) y2 = y2 > 0.f ? y2 : a.scale * y2;  // LeakyReLU (slope in `scale`), Conv3d path
-                if (a.flags & 1) y2 = fmaxf(y2, 0.f);
-                if (a.aux0) y2 = h_r[reg] + y2;
-                if (a.flags & 2) y2 = fmaxf(y2, 0.f);
-                a.out0[b * a.obs0 + co * DP + pix] = y2;
-            } else if (epi == EPI_GRU_ZR) {
-                const float sg = sigmoidf_(v);
-                if (co < a.hidden) a.out0[b * a.obs0 + co * DP + pix] = sg;
-                else a.out1[b * a.obs1 + (co - a.hidden) * DP + pix] = sg * h_r[reg];
-            } else {  // EPI_GRU_Q
-                const float q = tanhf_(v);
-                const float hn = (1.0f - z_r[reg]) * h_r[reg] + z_r[reg] * q;
-                a.out0[b * a.obs0 + co * DP + pix] = hn;
-                if (a.out1) a.out1[b * a.obs1 + co * DP + pix] = hn;
-            }
-        }
+        conv_epilogue<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
     }
 #ifdef NND_DBG_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
@@ -606,6 +482,7 @@ static int launch_shape(const ConvArgs& a, const TileCfg& cfg, dim3 grid, dim3 b
 
 int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W,
                 hipStream_t stream) {
+    if (L.arith != 0) return launch_conv_split(L, blob, io, epi, B, H, W, stream);
     NND_REQUIRE(io.src0.C + io.src1.C == L.Cin, "conv: source channels %d+%d != Cin %d", io.src0.C, io.src1.C, L.Cin);
     NND_REQUIRE(io.src1.C == 0 || io.src0.C % L.CI_T == 0, "conv: first source (%d ch) must be a multiple of %d", io.src0.C, L.CI_T);
     const int Hin = io.Hin > 0 ? io.Hin : H, Win = io.Win > 0 ? io.Win : W;
@@ -703,6 +580,7 @@ int conv_ci_t(int KH, int KW, int Cin, int stride, int Cout) {
 // bvec[part] == nullptr packs a zero bias (the caller adds it elsewhere).
 void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const float* const* bvec,
                const int* cout, float* blob, const int* ci_map, int cin_src) {
+    if (L.arith != 0) return pack_conv_split(L, nparts, w, bvec, cout, blob, ci_map, cin_src);
     if (!ci_map) cin_src = L.Cin;
     const int NT = L.KH * L.KW, NQ = L.CI_T / 8;
     float* wp = blob + L.w_off;

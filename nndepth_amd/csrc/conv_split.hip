@@ -1,0 +1,450 @@
+// Implicit-GEMM 2-D convolution (stride 1, zero "same" padding) on the gfx950 16-bit MFMA with fp32 operands carried
+// as SPLIT bf16 pieces — the route past the 157 TFLOP/s fp32-MFMA ceiling:
+//
+//   x = x0 + x1 + x2,  w = w0 + w1 + w2     (bf16 pieces by successive round-to-nearest of the residual: 3 x 8 = 24 bits)
+//   x*w ~= sum_{i+j<=2} x_i*w_j             (6 products; the dropped ones are <= 2^-24 |x||w|, an fp32 rounding)
+//   every product is an exact fp32 value (8 x 8 significand bits) and v_mfma_f32_32x32x16_bf16 accumulates in fp32.
+//
+// 6 MFMAs at 16x the fp32-MFMA rate = 0.375x the matrix time of conv_mfma.hip for the same result to fp32 rounding level
+// (measured error per op and drift over the 32-iteration recurrence: DESIGN.md §4, tests/test_gpu_split.py).  The exact
+// fp32 kernel stays the default; this one is selected per layer by ConvLayer::arith (nnd_update_block_desc.arithmetic).
+//
+// Mapping (D = A*B, same accumulator layout as the fp32 kernel, so conv_epilogue.h is shared):
+//   A = weights     pre-split on the host, packed in fragment order [cb][16-channel chunk][tap][piece][lane][8 x bf16]:
+//                   one coalesced 1 KiB dwordx4 load per wave per (tap, piece); never touches LDS
+//   B = activations fp32 in HBM (tile-major or NCHW); the staging threads split them while they build the halo patch in
+//                   LDS as [K-slice][sub-tile][row][col][piece][16 channels] bf16: a lane's B fragment (8 consecutive
+//                   channels of one pixel and piece) is one ds_read_b128 at lane_base + immediate
+// Workgroup = wco x ks waves on P = 2 independent 4x8-pixel sub-tiles (linear sub-tile index 2*blockIdx.x + pp, so 255
+// sub-tiles pair into 128 workgroups without a ragged rectangle): wave (cbi, kj) owns output-channel block
+// blockIdx.y*wco + cbi, both sub-tiles (each A fragment feeds two MFMAs — at 16x the MFMA rate the weight stream, not the
+// matrix pipe, is what limits a 32-pixel tile) and K-slice kj: of every super-chunk of ks*16 input channels staged in LDS
+// it multiplies channels [kj*16, kj*16+16); the ks partial tiles are summed through LDS at the end.
+// LDS image: position stride PS = pieces*32 + 16 bytes (an odd number of 16-B units) and row stride ROWB with
+// ROWB/16 = 8 (mod 16); with the lane -> pixel permutation of lane_pixel() the 16 lanes that one ds_read_b128 cycle
+// serves (lanes {0-3,12-15,20-27}, {4-11,16-19,28-31} of each half-wave) hit 16 different 16-B bank groups for every tap.
+//
+// Replaces (when selected) the same nn.Conv2d calls as conv_mfma.hip: nndepth/blocks/update_block.py:57-65,26-36,97-112,
+// nndepth/blocks/gru.py:22-37,53-61.
+#include "common.h"
+#include "conv_epilogue.h"
+#include "layout.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace nnd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int split_pos_bytes(int NS) { return NS * 32 + 16; }
+__host__ __device__ constexpr int split_row_bytes(int PC, int NS) {
+    int rb = (PC * split_pos_bytes(NS) + 15) / 16;
+    while (rb % 16 != 8) ++rb;
+    return rb * 16;
+}
+
+// lane (0..31 of a half-wave) -> pixel index r*8 + c of the 4x8 sub-tile: the two lane groups that ds_read_b128 serves in
+// separate cycles get rows {0,1} and rows {2,3}
+__device__ __forceinline__ int lane_pixel(int l31) {
+    const bool g0 = (l31 < 4) || (l31 >= 12 && l31 < 16) || (l31 >= 20 && l31 < 28);
+    const int idx = g0 ? (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12)) : (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16));
+    return (g0 ? 0 : 16) + idx;
+}
+
+// 8 fp32 -> NS bf16x8 pieces (round-to-nearest of the running residual; the subtractions are exact in fp32)
+template <int NS>
+__device__ __forceinline__ void split_pieces(const float (&x)[8], uint4 (&out)[NS]) {
+    float res[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) res[j] = x[j];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (__bf16)res[j];
+            res[j] -= (float)v[j];
+        }
+        out[s] = __builtin_bit_cast(uint4, v);
+    }
+}
+
+template <int KH, int KW, int NS, int P, int NU>
+__global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
+    constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
+    constexpr int PR = 4 + KH - 1, PC = 8 + KW - 1, NPOS = PR * PC;
+    constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PC, NS), SUBB = PR * ROWB;
+    constexpr int NPROD = NS * (NS + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = a.wco, ks = a.ks;
+    const int cbi = wave % wco, kj = wave / wco;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int pxl = lane_pixel(l31), r = pxl >> 3, c = pxl & 7;
+    const int cb = blockIdx.y * wco + cbi;
+    const bool active = cb * 32 < a.Cout;
+    const int b = blockIdx.z;
+    const int Hin = a.Hin, Win = a.Win;
+    const long SP = a.ls.plane;
+    const int SCH = ks * 16;  // channels per super-chunk
+
+    int ty0[P], tx0[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        const int t = blockIdx.x * P + pp;
+        const bool valid = t < a.npos;  // npos = number of sub-tiles of one image
+        ty0[pp] = valid ? (t / a.tiles_x) * 4 : (1 << 20);  // an absent sub-tile lies outside the image: staged as zeros, never stored
+        tx0[pp] = valid ? (t % a.tiles_x) * 8 : 0;
+    }
+
+    // ---- staging units of this thread: unit = (sub-tile, patch position, 8 consecutive channels of the super-chunk)
+    const int nunits = P * NPOS * 2 * ks;
+    int goff[NU], loff[NU], cho[NU];
+    bool inimg[NU], own[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = tid + i * nthreads;
+        own[i] = u < nunits;
+        const int pos = u % NPOS, rest = u / NPOS;
+        const int pp = rest % P, oct = rest / P;
+        const int pr = pos / PC, pc = pos - pr * PC;
+        int gy = 0, gx = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q == pp) {
+                gy = ty0[q] + pr - PH;
+                gx = tx0[q] + pc - PW;
+            }
+        inimg[i] = own[i] && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+        goff[i] = inimg[i] ? (int)pix_off(a.ls, gy, gx) : 0;
+        loff[i] = (oct >> 1) * (P * SUBB) + pp * SUBB + pr * ROWB + pc * PS + (oct & 1) * 16;
+        cho[i] = oct * 8;
+    }
+
+    f32x16 acc[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[pp][i] = 0.f;
+
+    const int nchunks = a.nchunks;  // 16-channel chunks
+    const int nsuper = (nchunks + ks - 1) / ks;
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(active ? cb : 0) * nchunks * (NT * NS * 64) + lane;
+    float stage[NU][8];
+
+    auto chunk_src = [&](int K, const float*& src, int& climit) {
+        const int cbase = K * SCH;
+        if (cbase < a.c0) {
+            src = a.src0 + b * a.bs0 + (long)cbase * SP;
+            climit = a.c0 - cbase;
+        } else {
+            const int cc = cbase - a.c0;
+            src = a.src1 + b * a.bs1 + (long)cc * SP;
+            climit = a.c1 - cc;
+        }
+    };
+    // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_x
+    auto load_x = [&](int K) {
+        const float* src;
+        int climit;
+        chunk_src(K, src, climit);
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = cho[i] + j;
+                stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
+            }
+    };
+    auto store_x = [&](int K) {
+        const float* src;
+        int climit;
+        chunk_src(K, src, climit);
+        unsigned char* buf = lds_raw + (K & 1) * (ks * P * SUBB);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (inimg[i] && cho[i] + j < climit) ? stage[i][j] : 0.f;
+            uint4 pieces[NS];
+            split_pieces<NS>(v, pieces);
+            if (own[i]) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(buf + loff[i] + s * 32) = pieces[s];
+            }
+        }
+    };
+    auto a_ptr = [&](int K) {
+        int ch = K * ks + kj;
+        ch = ch < nchunks ? ch : 0;  // waves past the last chunk re-read chunk 0: harmless, their MFMAs are skipped
+        return wbase + (size_t)ch * (NT * NS * 64);
+    };
+    auto load_a = [&](uint4 (&dst)[NS], const uint4* wc, int t) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dst[s] = wc[(t * NS + s) * 64];
+    };
+
+    const int lane_base = kj * (P * SUBB) + r * ROWB + c * PS + h2 * 16;
+
+    uint4 abuf[2][NS];
+    load_a(abuf[0], a_ptr(0), 0);
+    load_x(0);
+    store_x(0);
+    __syncthreads();
+
+    auto chunk = [&](int K, auto par_c) {
+        constexpr int par = decltype(par_c)::value;
+        const bool more = (K + 1 < nsuper);
+        if (more) load_x(K + 1);
+        const uint4* wc = a_ptr(K);
+        const uint4* wn = a_ptr(more ? K + 1 : K);
+        const bool mine = K * ks + kj < nchunks;
+        const unsigned char* xb = lds_raw + (K & 1) * (ks * P * SUBB) + lane_base;
+        // B fragments rotate through 3 slots at (tap, sub-tile) granularity: unit u = t*P + pp lives in slot u % 3 and the
+        // reads of unit u + 2 are issued when unit u starts (its slot was freed by unit u - 1)
+        constexpr int NUNIT = NT * P, NSLOT = 3;
+        uint4 bq[NSLOT][NS];
+        auto read_b = [&](int u, uint4 (&dst)[NS]) {
+            const int t = u / P, pp = u % P;
+            const int dy = t / KW, dx = t % KW;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + dy * ROWB + dx * PS + s * 32);
+        };
+        read_b(0, bq[0]);
+        if (NUNIT > 1) read_b(1, bq[1]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint4(&ac)[NS] = abuf[(par + t) & 1];
+            uint4(&an)[NS] = abuf[(par + t + 1) & 1];
+            if (t + 1 < NT) load_a(an, wc, t + 1);
+            else load_a(an, wn, 0);
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                const int u = t * P + pp;
+                if (u + 2 < NUNIT) read_b(u + 2, bq[(u + 2) % NSLOT]);
+                if (mine) {
+                    // small products first: x_i * w_j with i + j descending, so they are not absorbed one by one into a
+                    // large partial sum any earlier than necessary
+#pragma unroll
+                    for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int i = 0; i <= sum; ++i)
+                            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[sum - i]),
+                                                                             __builtin_bit_cast(bf16x8, bq[u % NSLOT][i]), acc[pp], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_x(K + 1);
+        __syncthreads();
+    };
+    static_assert(NPROD == NS * (NS + 1) / 2, "product list");
+    if constexpr (NT % 2 == 0) {
+        for (int K = 0; K < nsuper; ++K) chunk(K, std::integral_constant<int, 0>{});
+    } else {
+        for (int K = 0; K < nsuper; K += 2) {
+            chunk(K, std::integral_constant<int, 0>{});
+            if (K + 1 < nsuper) chunk(K + 1, std::integral_constant<int, 1>{});
+        }
+    }
+
+    // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier); slice kj then
+    // owns registers [kj*16/ks, (kj+1)*16/ks) of the tile for the epilogue
+    float* red_all = reinterpret_cast<float*>(lds_raw);
+    constexpr int TS = P * 1024;
+    if (ks > 1) {
+        if (active) {
+            float* red = red_all + (size_t)(cbi * ks + kj) * TS + lane;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) red[pp * 1024 + reg * 64] = acc[pp][reg];
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const int nreg = 16 / ks, reg0 = kj * nreg;
+    if (ks > 1) {
+        const float* red = red_all + (size_t)(cbi * ks) * TS + lane;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (reg < reg0 || reg >= reg0 + nreg) continue;
+                float sum = red[pp * 1024 + reg * 64];
+                for (int j = 1; j < ks; ++j) sum += red[(size_t)j * TS + pp * 1024 + reg * 64];
+                acc[pp][reg] = sum;
+            }
+    }
+    int ys[P], xs[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        ys[pp] = ty0[pp] + r;
+        xs[pp] = tx0[pp] + c;
+    }
+    conv_epilogue<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
+}
+
+// --------------------------------------------------------------------------- host side
+namespace {
+struct SplitCfg {
+    int ny, wco, ks, ntiles, tiles_x;
+    size_t lds;
+};
+
+constexpr int SPLIT_P = 2, SPLIT_NU = 2, SPLIT_MAX_WAVES = 12;
+
+uint16_t bf16_rn(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_to_f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCfg* out) {
+    const int NS = L.arith;
+    const int PR = 4 + L.KH - 1, PC = 8 + L.KW - 1;
+    const size_t subb = (size_t)PR * split_row_bytes(PC, NS);
+    const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
+    const long px_wgs = (long)cdiv(ntiles, SPLIT_P) * B;
+    int force_ny = -1, force_ks = -1;
+    if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d", &force_ny, &force_ks);
+    double best = 1e30;
+    bool found = false;
+    for (int ny = 1; ny <= L.ncb; ++ny) {
+        if (L.ncb % ny != 0 || (force_ny > 0 && ny != force_ny)) continue;
+        const int wco = L.ncb / ny;
+        for (int ks : {1, 2, 4}) {
+            if (force_ks > 0 && ks != force_ks) continue;
+            const int waves = wco * ks;
+            if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
+            if (c1 > 0 && c0 % (ks * 16) != 0) continue;
+            if (SPLIT_P * PR * PC * 2 * ks > SPLIT_NU * 64 * waves) continue;  // staging units per thread
+            size_t lds = (size_t)2 * ks * SPLIT_P * subb;
+            const size_t red = ks > 1 ? (size_t)waves * SPLIT_P * 4096 : 0;
+            if (red > lds) lds = red;
+            if (lds > 160 * 1024) continue;
+            int wg_per_cu = (int)((160 * 1024) / lds);
+            if (wg_per_cu > SPLIT_MAX_WAVES / waves) wg_per_cu = SPLIT_MAX_WAVES / waves;
+            if (wg_per_cu < 1) wg_per_cu = 1;
+            const double rounds = std::ceil((double)px_wgs * ny / (256.0 * wg_per_cu));
+            const double simd_waves = std::ceil(waves * wg_per_cu / 4.0);
+            double t = rounds * simd_waves * cdiv(L.nchunks, ks);
+            t *= 1.0 + 0.03 * (ks - 1);       // split-K exchange
+            t *= 1.0 + 0.02 * (4 - (wco < 4 ? wco : 4));  // fewer waves share one staged patch
+            if (t < best) {
+                best = t;
+                *out = {ny, wco, ks, ntiles, tiles_x, lds};
+                found = true;
+            }
+        }
+    }
+    return found;
+}
+
+template <int KH, int KW, int NS>
+int launch_split_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    auto kern = conv_split_kernel<KH, KW, NS, SPLIT_P, SPLIT_NU>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;  // per instantiation; idempotent, so a benign race at worst
+        if (!raised) {
+            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    return NND_OK;
+}
+}  // namespace
+
+bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith) {
+    if (arith != 3 || stride != 1 || Cin % 16 != 0) return false;
+    return (KH == 3 && KW == 3) || (KH == 1 && KW == 5) || (KH == 5 && KW == 1) || (KH == 1 && KW == 1);
+}
+
+int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W, hipStream_t stream) {
+    NND_REQUIRE(conv_split_supported(L.KH, L.KW, L.Cin, L.stride, L.arith), "conv_split: %dx%d Cin=%d stride %d arith %d not built",
+                L.KH, L.KW, L.Cin, L.stride, L.arith);
+    NND_REQUIRE(io.src0.C + io.src1.C == L.Cin, "conv_split: source channels %d+%d != Cin %d", io.src0.C, io.src1.C, L.Cin);
+    NND_REQUIRE(L.CI_T == 16 && L.nchunks * 16 == L.Cin, "conv_split: layer was not planned for 16-channel chunks");
+    NND_REQUIRE((long)(L.Cin + 64) * tiled_plane(H, W) < (1L << 31), "conv_split: plane offsets exceed 32 bits");
+    SplitCfg cfg;
+    NND_REQUIRE(pick_split(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv_split: no configuration for %dx%d Cin=%d (%d+%d)", L.KH,
+                L.KW, L.Cin, io.src0.C, io.src1.C);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = io.src0.ptr; a.bs0 = io.src0.bstride; a.c0 = io.src0.C;
+    a.src1 = io.src1.ptr; a.bs1 = io.src1.bstride; a.c1 = io.src1.C;
+    a.wpk = blob + L.w_off;
+    a.bias = blob + L.b_off;
+    a.out0 = io.out0.ptr; a.obs0 = io.out0.bstride;
+    a.out1 = io.out1.ptr; a.obs1 = io.out1.bstride;
+    a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
+    a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
+    a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
+    a.ls = make_lay(H, W, io.src_tiled);
+    a.ld = make_lay(H, W, io.dst_tiled);
+    a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
+    a.Hin = H; a.Win = W; a.flags = io.flags;
+    a.cscale = L.s_off >= 0 ? blob + L.s_off : nullptr;
+    NND_REQUIRE(epi != EPI_AFFINE || a.cscale, "conv_split: EPI_AFFINE needs a packed scale vector");
+    a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks; a.npos = cfg.ntiles;
+    a.scale = io.scale;
+    dim3 grid(cdiv(cfg.ntiles, SPLIT_P), cfg.ny, B), block(64 * cfg.wco * cfg.ks);
+    static const bool verbose = getenv("NND_CONV_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[nnd] conv_split %dx%d Cin=%d Cout=%d pieces=%d: ny=%d, wco=%d, ks=%d, grid %ux%ux%u, lds %zu B\n", L.KH, L.KW,
+                L.Cin, L.Cout, L.arith, cfg.ny, cfg.wco, cfg.ks, grid.x, grid.y, grid.z, cfg.lds);
+    int rc = NND_ERR_UNSUPPORTED;
+    if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 3>(a, grid, block, cfg.lds, stream);
+    else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 3>(a, grid, block, cfg.lds, stream);
+    else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 3>(a, grid, block, cfg.lds, stream);
+    else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 3>(a, grid, block, cfg.lds, stream);
+    if (rc != NND_OK) return rc;
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+// Host packer: same (cout, cin_src, KH, KW) inputs as pack_conv; blob order [cb][chunk][tap][piece][lane][8] bf16 with
+// lane = h*32 + (co % 32) holding channels chunk*16 + 8h + 0..7 (the A operand of v_mfma_f32_32x32x16_bf16).
+void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, const float* const* bvec, const int* cout, float* blob,
+                     const int* ci_map, int cin_src) {
+    if (!ci_map) cin_src = L.Cin;
+    const int NT = L.KH * L.KW, NS = L.arith;
+    uint16_t* wp = reinterpret_cast<uint16_t*>(blob + L.w_off);
+    float* bp = blob + L.b_off;
+    memset(wp, 0, sizeof(float) * L.w_floats());
+    memset(bp, 0, sizeof(float) * L.b_floats());
+    int co0 = 0;
+    for (int part = 0; part < nparts; ++part) {
+        for (int col = 0; col < cout[part]; ++col) {
+            const int co = co0 + col, cb = co / 32, i = co % 32;
+            bp[co] = bvec[part] ? bvec[part][col] : 0.f;
+            for (int ci = 0; ci < L.Cin; ++ci) {
+                const int chunk = ci / 16, cl = ci % 16, h = cl / 8, j = cl % 8, lane = h * 32 + i;
+                for (int t = 0; t < NT; ++t) {
+                    float res = w[part][((size_t)col * cin_src + (ci_map ? ci_map[ci] : ci)) * NT + t];
+                    for (int s = 0; s < NS; ++s) {
+                        const uint16_t piece = bf16_rn(res);
+                        res -= bf16_to_f(piece);
+                        wp[((((((size_t)cb * L.nchunks + chunk) * NT + t) * NS + s) * 64 + lane) * 8) + j] = piece;
+                    }
+                }
+            }
+        }
+        co0 += cout[part];
+    }
+}
+
+}  // namespace nnd

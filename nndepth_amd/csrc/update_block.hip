@@ -42,9 +42,12 @@ struct Plan {
     int64_t total;
 };
 
-static ConvLayer mk(int KH, int KW, int Cin, int Cout, int64_t* off) {
+// arith != 0: the layer runs on conv_split.hip (fp32 operands as split bf16 pieces), if that kernel is built for its shape
+static ConvLayer mk(int KH, int KW, int Cin, int Cout, int64_t* off, int arith = 0) {
     ConvLayer l;
-    const int CI_T = conv_ci_t(KH, KW, Cin, 1, Cout);
+    if (arith != 0 && !conv_split_supported(KH, KW, Cin, 1, arith)) arith = 0;
+    const int CI_T = arith ? 16 : conv_ci_t(KH, KW, Cin, 1, Cout);
+    l.arith = arith;
     l.KH = KH; l.KW = KW; l.Cin = Cin; l.Cout = Cout; l.CI_T = CI_T;
     l.nchunks = cdiv(Cin, CI_T);
     l.ncb = cdiv(Cout, 32);
@@ -62,32 +65,39 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     NND_REQUIRE(ctx > 0 && ctx % 8 == 0, "update_block: context_dim %d must be a positive multiple of 8", ctx);
     NND_REQUIRE(cp > 0 && (fc == 1 || fc == 2) && mc > 0 && mc % 9 == 0, "update_block: bad cor_planes/flow_channels/mask_channels");
     NND_REQUIRE(d->gru_kind == 0 || d->gru_kind == 1, "update_block: gru_kind must be 0 (sep_conv) or 1 (conv_gru)");
+    NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3, "update_block: arithmetic must be 0 (fp32 MFMA) or 3 (bf16x3 split)");
+    // arithmetic == 3: every MFMA conv whose shape conv_split.hip builds takes the split-bf16 kernel, except convc1 and mask.2
+    // (their weights are consumed by the fused lookup / upsample kernels in the fp32 packing); NND_SPLIT_MASK (diagnostic)
+    // restricts it to a subset, bit = ConvId (e.g. 2 = encoder.convc2 only)
+    unsigned split_mask = ~0u;
+    if (const char* e = getenv("NND_SPLIT_MASK")) split_mask = (unsigned)strtoul(e, nullptr, 0);
+    auto ar = [&](int id) { return (d->arithmetic != 0 && ((split_mask >> id) & 1u)) ? d->arithmetic : 0; };
     p->d = *d;
     p->sep = d->gru_kind == 0;
     int64_t off = 0;
     const int gin = hid + ctx + hid;
     p->L[C_C1] = mk(1, 1, cp, 256, &off);
-    p->L[C_C2] = mk(3, 3, 256, 192, &off);
+    p->L[C_C2] = mk(3, 3, 256, 192, &off, ar(C_C2));
     p->f1_w = off; off += (int64_t)128 * fc * 49;
     p->f1_b = off; off += 128;
-    p->L[C_F2] = mk(3, 3, 128, 64, &off);
-    p->L[C_CV] = mk(3, 3, 256, hid - fc, &off);
+    p->L[C_F2] = mk(3, 3, 128, 64, &off, ar(C_F2));
+    p->L[C_CV] = mk(3, 3, 256, hid - fc, &off, ar(C_CV));
     for (int pass = 0; pass < (p->sep ? 2 : 1); ++pass) {
         const int kh = p->sep ? (pass == 0 ? 1 : 5) : 3, kw = p->sep ? (pass == 0 ? 5 : 1) : 3;
         const int zr = pass == 0 ? C_ZR1 : C_ZR2, q = pass == 0 ? C_Q1 : C_Q2;
-        p->L[zr] = mk(kh, kw, gin, 2 * hid, &off);
-        p->L[q] = mk(kh, kw, gin, hid, &off);
-        p->L[zr - C_ZR1 + C_ZR1X] = mk(kh, kw, 2 * hid, 2 * hid, &off);
-        p->L[q - C_ZR1 + C_ZR1X] = mk(kh, kw, 2 * hid, hid, &off);
-        p->L[zr - C_ZR1 + C_ZR1C] = mk(kh, kw, ctx, 2 * hid, &off);
-        p->L[q - C_ZR1 + C_ZR1C] = mk(kh, kw, ctx, hid, &off);
+        p->L[zr] = mk(kh, kw, gin, 2 * hid, &off, ar(zr));
+        p->L[q] = mk(kh, kw, gin, hid, &off, ar(q));
+        p->L[zr - C_ZR1 + C_ZR1X] = mk(kh, kw, 2 * hid, 2 * hid, &off, ar(zr - C_ZR1 + C_ZR1X));
+        p->L[q - C_ZR1 + C_ZR1X] = mk(kh, kw, 2 * hid, hid, &off, ar(q - C_ZR1 + C_ZR1X));
+        p->L[zr - C_ZR1 + C_ZR1C] = mk(kh, kw, ctx, 2 * hid, &off, ar(zr - C_ZR1 + C_ZR1C));
+        p->L[q - C_ZR1 + C_ZR1C] = mk(kh, kw, ctx, hid, &off, ar(q - C_ZR1 + C_ZR1C));
     }
     if (!p->sep)
         for (int base : {(int)C_ZR1X, (int)C_ZR1, (int)C_ZR1C}) {
             p->L[base + 2] = p->L[base];
             p->L[base + 3] = p->L[base + 1];
         }
-    p->L[C_FHM] = mk(3, 3, hid, 3 * hid, &off);  // flow_head.conv1 (hid) and mask.0 (2*hid): same input h, both ReLU -> one conv
+    p->L[C_FHM] = mk(3, 3, hid, 3 * hid, &off, ar(C_FHM));  // flow_head.conv1 (hid) and mask.0 (2*hid): same input h, both ReLU -> one conv
     p->fc2_w = off; off += (int64_t)fc * hid * 9;
     p->fc2_b = off; off += 4;  // keep 16-B alignment of what follows
     p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off);
@@ -790,26 +800,29 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     return NND_OK;
 }
 
-static int conv2d_layer(int Cout, int Cin, int KH, int KW, ConvLayer* L, int64_t* total) {
+static int conv2d_layer(int Cout, int Cin, int KH, int KW, int arithmetic, ConvLayer* L, int64_t* total) {
     NND_REQUIRE(Cout > 0 && Cin > 0, "conv2d: bad channel counts");
     NND_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 1 && KW == 5) || (KH == 5 && KW == 1),
                 "conv2d: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", KH, KW);
+    NND_REQUIRE(arithmetic == 0 || conv_split_supported(KH, KW, Cin, 1, arithmetic),
+                "conv2d: arithmetic %d not built for %dx%d with %d input channels (3 = bf16x3 split, Cin %% 16 == 0)", arithmetic, KH, KW, Cin);
     int64_t off = 0;
-    *L = mk(KH, KW, Cin, Cout, &off);
+    *L = mk(KH, KW, Cin, Cout, &off, arithmetic);
     if (total) *total = off;
     return NND_OK;
 }
 
-int64_t nnd_conv2d_packed_floats(int Cout, int Cin, int KH, int KW) {
+int64_t nnd_conv2d_packed_floats_ex(int Cout, int Cin, int KH, int KW, int arithmetic) {
     ConvLayer L;
     int64_t total;
-    if (conv2d_layer(Cout, Cin, KH, KW, &L, &total) != NND_OK) return NND_ERR_INVALID;
+    if (conv2d_layer(Cout, Cin, KH, KW, arithmetic, &L, &total) != NND_OK) return NND_ERR_INVALID;
     return total;
 }
+int64_t nnd_conv2d_packed_floats(int Cout, int Cin, int KH, int KW) { return nnd_conv2d_packed_floats_ex(Cout, Cin, KH, KW, 0); }
 
-int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW, float* packed_host) {
+int nnd_conv2d_pack_ex(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW, int arithmetic, float* packed_host) {
     ConvLayer L;
-    int rc = conv2d_layer(Cout, Cin, KH, KW, &L, nullptr);
+    int rc = conv2d_layer(Cout, Cin, KH, KW, arithmetic, &L, nullptr);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(w_host && b_host && packed_host, "conv2d_pack: null pointer");
     const float* w[1] = {w_host};
@@ -818,11 +831,14 @@ int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin,
     pack_conv(L, 1, w, b, co, packed_host);
     return NND_OK;
 }
+int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW, float* packed_host) {
+    return nnd_conv2d_pack_ex(w_host, b_host, Cout, Cin, KH, KW, 0, packed_host);
+}
 
-int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
-                       int KW, int relu, void* stream) {
+int nnd_conv2d_forward_ex(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
+                          int KW, int relu, int arithmetic, void* stream) {
     ConvLayer L;
-    int rc = conv2d_layer(Cout, Cin, KH, KW, &L, nullptr);
+    int rc = conv2d_layer(Cout, Cin, KH, KW, arithmetic, &L, nullptr);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed_dev && x && y && B > 0 && H > 0 && W > 0, "conv2d_forward: bad argument");
     const int64_t n = (int64_t)H * W;
@@ -830,6 +846,10 @@ int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B,
     io.src0 = act(const_cast<float*>(x), Cin * n, Cin);
     io.out0 = act(y, Cout * n, Cout);
     return launch_conv(L, packed_dev, io, relu ? EPI_RELU : EPI_LINEAR, B, H, W, (hipStream_t)stream);
+}
+int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
+                       int KW, int relu, void* stream) {
+    return nnd_conv2d_forward_ex(packed_dev, x, y, B, Cin, H, W, Cout, KH, KW, relu, 0, stream);
 }
 
 int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
@@ -868,7 +888,7 @@ int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed
 int nnd_mask_upsample_forward(const float* packed_dev, const float* x, const float* flow, float* out, int B, int Cin, int H,
                               int W, int rate, void* stream) {
     ConvLayer L;
-    int rc = conv2d_layer(9 * rate * rate, Cin, 1, 1, &L, nullptr);
+    int rc = conv2d_layer(9 * rate * rate, Cin, 1, 1, 0, &L, nullptr);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed_dev && x && flow && out && B > 0 && H > 0 && W > 0, "mask_upsample_forward: bad argument");
     NND_REQUIRE(mask_upsample_supported(rate, Cin, 1), "mask_upsample_forward: rate %d / Cin %d not built", rate, Cin);

@@ -84,17 +84,19 @@ def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, rate: int) -> torch.
 
 # ------------------------------------------------------------------------ generic conv2d
 class Conv2d:
-    """One packed stride-1 "same" convolution (1x1, 3x3, 1x5, 5x1) on the fp32-MFMA kernel."""
+    """One packed stride-1 "same" convolution (1x1, 3x3, 1x5, 5x1): arithmetic "fp32" = the exact fp32-MFMA kernel,
+    "bf16x3" = fp32 operands as 3 bf16 pieces on the bf16 MFMA (csrc/conv_split.hip, Cin % 16 == 0)."""
 
-    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, device="cuda"):
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, device="cuda", arithmetic: str = "fp32"):
         self.Cout, self.Cin, self.KH, self.KW = (int(s) for s in weight.shape)
-        n = int(lib.nnd_conv2d_packed_floats(self.Cout, self.Cin, self.KH, self.KW))
+        self.arith = UpdateBlockEngine.ARITHMETIC[arithmetic]
+        n = int(lib.nnd_conv2d_packed_floats_ex(self.Cout, self.Cin, self.KH, self.KW, self.arith))
         if n <= 0:
             check(n, "conv2d_packed_floats")
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = bias.detach().to("cpu", torch.float32).contiguous()
         blob = torch.empty(n, dtype=torch.float32)
-        check(lib.nnd_conv2d_pack(_p(w), _p(b), self.Cout, self.Cin, self.KH, self.KW, _p(blob)), "conv2d_pack")
+        check(lib.nnd_conv2d_pack_ex(_p(w), _p(b), self.Cout, self.Cin, self.KH, self.KW, self.arith, _p(blob)), "conv2d_pack")
         self.packed_host = blob
         self.packed = blob.to(device) if device is not None else None
 
@@ -106,8 +108,8 @@ class Conv2d:
             raise NndError(f"conv2d: input has {Cin} channels, weights expect {self.Cin}")
         y = torch.empty((B, self.Cout, H, W), dtype=torch.float32, device=d)
         with torch.cuda.device(d):
-            check(lib.nnd_conv2d_forward(_p(self.packed), _p(x), _p(y), B, Cin, H, W, self.Cout, self.KH, self.KW,
-                                         int(relu), _stream(d)), "conv2d_forward")
+            check(lib.nnd_conv2d_forward_ex(_p(self.packed), _p(x), _p(y), B, Cin, H, W, self.Cout, self.KH, self.KW,
+                                            int(relu), self.arith, _stream(d)), "conv2d_forward")
         return y
 
 
@@ -137,13 +139,18 @@ def update_block_keys(gru: str = "sep_conv") -> List[str]:
 class UpdateBlockEngine:
     """Packed parameters + workspace for one BasicUpdateBlock configuration."""
 
+    ARITHMETIC = {"fp32": 0, "bf16x3": 3}
+
     def __init__(self, hidden_dim: int, context_dim: int, cor_planes: int, flow_channels: int,
-                 mask_channels: int, gru: str = "sep_conv"):
+                 mask_channels: int, gru: str = "sep_conv", arithmetic: str = "fp32"):
         if gru not in ("sep_conv", "conv_gru"):
             raise NndError(f"unknown gru kind {gru!r}")
+        if arithmetic not in self.ARITHMETIC:
+            raise NndError(f"unknown arithmetic {arithmetic!r} (fp32 = exact fp32 MFMA, bf16x3 = 3-piece split on the bf16 MFMA)")
         self.gru = gru
+        self.arithmetic = arithmetic
         self.desc = UpdateBlockDesc(hidden_dim, context_dim, cor_planes, flow_channels, mask_channels,
-                                    0 if gru == "sep_conv" else 1)
+                                    0 if gru == "sep_conv" else 1, self.ARITHMETIC[arithmetic])
         n = lib.nnd_update_block_packed_floats(C.byref(self.desc))
         if n <= 0:
             check(int(n), "update_block_packed_floats")

@@ -65,8 +65,9 @@ class BaseRAFTStereo(nn.Module):
     def __init__(self, iters: int = 12, fnet_dim: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, hip_encoder: bool = True, **kwargs):
+                 fused_loop: bool = True, hip_encoder: bool = True, arithmetic: str = "fp32", **kwargs):
         super().__init__()
+        self.arithmetic = arithmetic  # convolutions of the fused loop: "fp32" (exact) or "bf16x3" (split bf16 MFMA)
         self.iters, self.fnet_dim, self.hidden_dim, self.context_dim = iters, fnet_dim, hidden_dim, context_dim
         self.corr_levels, self.corr_radius = corr_levels, corr_radius
         self.tracing, self.include_preprocessing = tracing, include_preprocessing
@@ -76,7 +77,7 @@ class BaseRAFTStereo(nn.Module):
         self.fnet = BasicEncoder(output_dim=fnet_dim)
         self.cnet_proj = nn.Sequential(nn.Conv2d(fnet_dim, context_dim + hidden_dim, 3, padding=1), nn.ReLU(False))
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=corr_levels * (2 * corr_radius + 1),
-                                             flow_channel=1, context_dim=context_dim, spatial_scale=8)
+                                             flow_channel=1, context_dim=context_dim, spatial_scale=8, arithmetic=arithmetic)
         self.corr_fn = CorrBlock1D
         self.weights, self.strict_load = weights, strict_load
         if weights is not None:
