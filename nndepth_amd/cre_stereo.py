@@ -122,8 +122,9 @@ class CREStereoBase(nn.Module):
                  max_disp: int = 192, num_fnet_channels: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  search_num: int = 9, mixed_precision: bool = False, test_mode: bool = False, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, hip_encoder: bool = True, **kwargs):
+                 fused_loop: bool = True, hip_encoder: bool = True, arithmetic: str = "fp32", **kwargs):
         super().__init__()
+        self.arithmetic = arithmetic  # update-block convolutions: "fp32" (exact) or "bf16x3" (split bf16 MFMA)
         if fnet_cls != "basic_encoder" or update_cls != "basic_update_block":
             raise ValueError("CREStereoBase: only basic_encoder / basic_update_block exist (as in the reference)")
         if context_dim != hidden_dim:
@@ -139,7 +140,7 @@ class CREStereoBase(nn.Module):
         self.fnet = BasicEncoder(output_dim=num_fnet_channels, norm_fn="instance", dropout=0)
         self.fnet_ds = 8
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=4 * 9, flow_channel=2,
-                                             context_dim=context_dim, spatial_scale=self.fnet_ds)
+                                             context_dim=context_dim, spatial_scale=self.fnet_ds, arithmetic=arithmetic)
         self.self_att_fn = LocalFeatureTransformer(num_fnet_channels, 8, ["self"], "linear")
         self.cross_att_fn = LocalFeatureTransformer(num_fnet_channels, 8, ["cross"], "linear")
         self.conv_offset_16 = nn.Conv2d(num_fnet_channels, 2 * search_num, 3, padding=1)

@@ -38,6 +38,30 @@ namespace nnd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef NND_SPLIT_AD
+#define NND_SPLIT_AD 1      // steps of lookahead of the weight-fragment stream
+#endif
+#ifndef NND_SPLIT_SPREAD
+#define NND_SPLIT_SPREAD 0  // 1: spread the staging of the next super-chunk over the MFMA steps of the current one
+#endif
+#ifndef NND_SPLIT_BSLOTS
+#define NND_SPLIT_BSLOTS 3  // register sets of the activation fragments (lookahead = sets - 1 units of 6 MFMAs)
+#endif
+
+#ifdef NND_DBG_STAMPS
+// debug build only: per-workgroup phase timestamps (s_memrealtime, 100 MHz) for scripts/stamps_split.py
+__device__ unsigned long long g_split_stamps[4096 * 8];
+#define NND_SSTAMP(i)                                                                                  \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
+            if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();        \
+        }                                                                                              \
+    } while (0)
+#else
+#define NND_SSTAMP(i)
+#endif
+
 __host__ __device__ constexpr int split_pos_bytes(int NS) { return NS * 32 + 16; }
 __host__ __device__ constexpr int split_row_bytes(int PC, int NS) {
     int rb = (PC * split_pos_bytes(NS) + 15) / 16;
@@ -78,6 +102,7 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
     constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PC, NS), SUBB = PR * ROWB;
     constexpr int NPROD = NS * (NS + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    NND_SSTAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -147,36 +172,40 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
             climit = a.c1 - cc;
         }
     };
-    // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_x
-    auto load_x = [&](int K) {
+    // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_unit.
+    // Staging is per unit so that the chunk loop can spread it between its MFMA steps (NND_SPLIT_SPREAD).
+    auto load_unit = [&](int K, int i) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
 #pragma unroll
-        for (int i = 0; i < NU; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ci = cho[i] + j;
-                stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int ci = cho[i] + j;
+            stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
+        }
     };
-    auto store_x = [&](int K) {
+    auto store_unit = [&](int K, int i) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
         unsigned char* buf = lds_raw + (K & 1) * (ks * P * SUBB);
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            float v[8];
+        for (int j = 0; j < 8; ++j) v[j] = (inimg[i] && cho[i] + j < climit) ? stage[i][j] : 0.f;
+        uint4 pieces[NS];
+        split_pieces<NS>(v, pieces);
+        if (own[i]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (inimg[i] && cho[i] + j < climit) ? stage[i][j] : 0.f;
-            uint4 pieces[NS];
-            split_pieces<NS>(v, pieces);
-            if (own[i]) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(buf + loff[i] + s * 32) = pieces[s];
-            }
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(buf + loff[i] + s * 32) = pieces[s];
         }
+    };
+    auto load_x = [&](int K) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) load_unit(K, i);
+    };
+    auto store_x = [&](int K) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) store_unit(K, i);
     };
     auto a_ptr = [&](int K) {
         int ch = K * ks + kj;
@@ -190,23 +219,30 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
 
     const int lane_base = kj * (P * SUBB) + r * ROWB + c * PS + h2 * 16;
 
-    uint4 abuf[2][NS];
-    load_a(abuf[0], a_ptr(0), 0);
+    // A fragments: a ring of AD + 1 register sets indexed by the global step g = K*NT + t; set g % NA holds step g, the
+    // loads of step g + AD are issued when step g starts (AD steps of MFMAs cover the L2 latency of the weight stream)
+    constexpr int AD = (NND_SPLIT_AD < NT ? NND_SPLIT_AD : NT), NA = AD + 1;
+    uint4 abuf[NA][NS];
+#pragma unroll
+    for (int g = 0; g < AD; ++g) load_a(abuf[g], a_ptr(0), g);
     load_x(0);
     store_x(0);
     __syncthreads();
+    NND_SSTAMP(1);
 
     auto chunk = [&](int K, auto par_c) {
         constexpr int par = decltype(par_c)::value;
         const bool more = (K + 1 < nsuper);
+#if !defined(NND_SPLIT_NO_STAGE) && !NND_SPLIT_SPREAD
         if (more) load_x(K + 1);
+#endif
         const uint4* wc = a_ptr(K);
-        const uint4* wn = a_ptr(more ? K + 1 : K);
+        const uint4* wn = a_ptr(more ? K + 1 : K);  // past the end: re-reads the last chunk, never used
         const bool mine = K * ks + kj < nchunks;
         const unsigned char* xb = lds_raw + (K & 1) * (ks * P * SUBB) + lane_base;
         // B fragments rotate through 3 slots at (tap, sub-tile) granularity: unit u = t*P + pp lives in slot u % 3 and the
         // reads of unit u + 2 are issued when unit u starts (its slot was freed by unit u - 1)
-        constexpr int NUNIT = NT * P, NSLOT = 3;
+        constexpr int NUNIT = NT * P, NSLOT = NND_SPLIT_BSLOTS;
         uint4 bq[NSLOT][NS];
         auto read_b = [&](int u, uint4 (&dst)[NS]) {
             const int t = u / P, pp = u % P;
@@ -215,19 +251,39 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
             for (int s = 0; s < NS; ++s)
                 dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + dy * ROWB + dx * PS + s * 32);
         };
-        read_b(0, bq[0]);
-        if (NUNIT > 1) read_b(1, bq[1]);
+#pragma unroll
+        for (int u = 0; u < NSLOT - 1 && u < NUNIT; ++u) read_b(u, bq[u]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            uint4(&ac)[NS] = abuf[(par + t) & 1];
-            uint4(&an)[NS] = abuf[(par + t + 1) & 1];
-            if (t + 1 < NT) load_a(an, wc, t + 1);
-            else load_a(an, wn, 0);
+            uint4(&ac)[NS] = abuf[(par + t) % NA];
+            uint4(&an)[NS] = abuf[(par + t + AD) % NA];
+#ifndef NND_SPLIT_NO_ALOAD
+            if (t + AD < NT) load_a(an, wc, t + AD);
+            else load_a(an, wn, t + AD - NT);
+#else
+            for (int s = 0; s < NS; ++s) an[s] = ac[s];
+#endif
+#if !defined(NND_SPLIT_NO_STAGE) && NND_SPLIT_SPREAD
+            // staging of the next super-chunk spread over this chunk's steps: unit i's loads go out at step i, its split +
+            // LDS stores run at step NT - NU + i (between MFMAs instead of in a VALU-only phase before the barrier)
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    if (t == (i < NT ? i : NT - 1)) load_unit(K + 1, i);
+                    if (NT > NU && t == NT - NU + i) store_unit(K + 1, i);
+                }
+            }
+#endif
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 const int u = t * P + pp;
-                if (u + 2 < NUNIT) read_b(u + 2, bq[(u + 2) % NSLOT]);
-                if (mine) {
+                if (u + NSLOT - 1 < NUNIT) read_b(u + NSLOT - 1, bq[(u + NSLOT - 1) % NSLOT]);
+#ifndef NND_SPLIT_NO_MFMA
+                if (mine)
+#else
+                if (mine && acc[0][0] == 123.f)
+#endif
+                {
                     // small products first: x_i * w_j with i + j descending, so they are not absorbed one by one into a
                     // large partial sum any earlier than necessary
 #pragma unroll
@@ -239,19 +295,31 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
                 }
             }
         }
-        if (more) store_x(K + 1);
+#ifndef NND_SPLIT_NO_STAGE
+        if (more && (!NND_SPLIT_SPREAD || NT <= NU)) store_x(K + 1);
+#endif
         __syncthreads();
     };
     static_assert(NPROD == NS * (NS + 1) / 2, "product list");
-    if constexpr (NT % 2 == 0) {
+    // the ring phase of a chunk's first step, (K*NT) % NA, must be a compile-time constant: walk the chunks in periods
+    constexpr int STEP = NT % NA;
+    if constexpr (STEP == 0) {
         for (int K = 0; K < nsuper; ++K) chunk(K, std::integral_constant<int, 0>{});
-    } else {
+    } else if constexpr (NA == 2) {
         for (int K = 0; K < nsuper; K += 2) {
             chunk(K, std::integral_constant<int, 0>{});
             if (K + 1 < nsuper) chunk(K + 1, std::integral_constant<int, 1>{});
         }
+    } else {
+        static_assert(NA == 3, "A-fragment ring of 2 or 3 register sets");
+        for (int K = 0; K < nsuper; K += 3) {
+            chunk(K, std::integral_constant<int, 0>{});
+            if (K + 1 < nsuper) chunk(K + 1, std::integral_constant<int, STEP>{});
+            if (K + 2 < nsuper) chunk(K + 2, std::integral_constant<int, (2 * STEP) % 3>{});
+        }
     }
 
+    NND_SSTAMP(2);
     // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier); slice kj then
     // owns registers [kj*16/ks, (kj+1)*16/ks) of the tile for the epilogue
     float* red_all = reinterpret_cast<float*>(lds_raw);
@@ -280,23 +348,31 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
                 acc[pp][reg] = sum;
             }
     }
+    NND_SSTAMP(3);
     int ys[P], xs[P];
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) {
         ys[pp] = ty0[pp] + r;
         xs[pp] = tx0[pp] + c;
     }
+#ifdef NND_SPLIT_NO_EPI
+    if (acc[0][0] != 123.456f) return;
+#endif
     conv_epilogue<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
+#ifdef NND_DBG_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    NND_SSTAMP(4);
 }
 
 // --------------------------------------------------------------------------- host side
 namespace {
 struct SplitCfg {
-    int ny, wco, ks, ntiles, tiles_x;
+    int ny, wco, ks, ntiles, tiles_x, nu;
     size_t lds;
 };
 
-constexpr int SPLIT_P = 2, SPLIT_NU = 2, SPLIT_MAX_WAVES = 12;
+constexpr int SPLIT_P = 2, SPLIT_MAX_WAVES = 12;
 
 uint16_t bf16_rn(float x) {
     uint32_t u;
@@ -330,7 +406,8 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
             const int waves = wco * ks;
             if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
             if (c1 > 0 && c0 % (ks * 16) != 0) continue;
-            if (SPLIT_P * PR * PC * 2 * ks > SPLIT_NU * 64 * waves) continue;  // staging units per thread
+            const int nu = cdiv(SPLIT_P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread (2 built, 4 for 1-2 waves)
+            if (nu > 4) continue;
             size_t lds = (size_t)2 * ks * SPLIT_P * subb;
             const size_t red = ks > 1 ? (size_t)waves * SPLIT_P * 4096 : 0;
             if (red > lds) lds = red;
@@ -343,9 +420,10 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
             double t = rounds * simd_waves * cdiv(L.nchunks, ks);
             t *= 1.0 + 0.03 * (ks - 1);       // split-K exchange
             t *= 1.0 + 0.02 * (4 - (wco < 4 ? wco : 4));  // fewer waves share one staged patch
+            if (nu > 2) t *= 1.2;                          // register-heavy staging variant
             if (t < best) {
                 best = t;
-                *out = {ny, wco, ks, ntiles, tiles_x, lds};
+                *out = {ny, wco, ks, ntiles, tiles_x, nu <= 2 ? 2 : 4, lds};
                 found = true;
             }
         }
@@ -353,9 +431,9 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
     return found;
 }
 
-template <int KH, int KW, int NS>
-int launch_split_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    auto kern = conv_split_kernel<KH, KW, NS, SPLIT_P, SPLIT_NU>;
+template <int KH, int KW, int NS, int NU>
+int launch_split_nu(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    auto kern = conv_split_kernel<KH, KW, NS, SPLIT_P, NU>;
     if (lds > 64 * 1024) {
         static bool raised = false;  // per instantiation; idempotent, so a benign race at worst
         if (!raised) {
@@ -365,6 +443,11 @@ int launch_split_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipSt
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     return NND_OK;
+}
+template <int KH, int KW, int NS>
+int launch_split_one(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
+    if (cfg.nu <= 2) return launch_split_nu<KH, KW, NS, 2>(a, grid, block, cfg.lds, stream);
+    return launch_split_nu<KH, KW, NS, 4>(a, grid, block, cfg.lds, stream);
 }
 }  // namespace
 
@@ -407,10 +490,10 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
         fprintf(stderr, "[nnd] conv_split %dx%d Cin=%d Cout=%d pieces=%d: ny=%d, wco=%d, ks=%d, grid %ux%ux%u, lds %zu B\n", L.KH, L.KW,
                 L.Cin, L.Cout, L.arith, cfg.ny, cfg.wco, cfg.ks, grid.x, grid.y, grid.z, cfg.lds);
     int rc = NND_ERR_UNSUPPORTED;
-    if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 3>(a, grid, block, cfg.lds, stream);
-    else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 3>(a, grid, block, cfg.lds, stream);
-    else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 3>(a, grid, block, cfg.lds, stream);
-    else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 3>(a, grid, block, cfg.lds, stream);
+    if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 3>(a, cfg, grid, block, stream);
+    else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 3>(a, cfg, grid, block, stream);
+    else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 3>(a, cfg, grid, block, stream);
+    else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 3>(a, cfg, grid, block, stream);
     if (rc != NND_OK) return rc;
     NND_LAUNCH_CHECK();
     return NND_OK;
@@ -447,4 +530,9 @@ void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, cons
     }
 }
 
+#ifdef NND_DBG_STAMPS
+extern "C" int nnd_debug_read_split_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // namespace nnd

@@ -159,15 +159,17 @@ class IGEVStereoBase(nn.Module):
     def __init__(self, update_cls: str = "basic_update_block", cv_groups: int = 8, iters: int = 12, hidden_dim: int = 128,
                  context_dim: int = 128, corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True):
+                 fused_loop: bool = True, arithmetic: str = "fp32"):
         super().__init__()
+        self.arithmetic = arithmetic  # update-block convolutions: "fp32" (exact) or "bf16x3" (split bf16 MFMA)
         if update_cls != "basic_update_block":
             raise KeyError(update_cls)
         self.fnet = self._init_fnet()
         self.iters, self.hidden_dim, self.context_dim = iters, hidden_dim, context_dim
         self.cv_groups, self.corr_levels, self.corr_radius = cv_groups, corr_levels, corr_radius
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, context_dim=context_dim, flow_channel=1,
-                                             cor_planes=corr_levels * (2 * corr_radius + 1) * cv_groups * 2, spatial_scale=4)
+                                             cor_planes=corr_levels * (2 * corr_radius + 1) * cv_groups * 2, spatial_scale=4,
+                                             arithmetic=arithmetic)
         self.cv_regularizer = self._init_cost_volume_filter()
         self.corr_fn = GeometryAwareCostVolume
         self.cv_squeezer = nn.Conv3d(cv_groups, 1, 3, 1, 1)

@@ -1,0 +1,42 @@
+"""Workgroup-shape sweep of conv_split.hip: launch time of every bf16x3 loop conv for forced (ny, ks) = (output-channel groups
+across workgroups, intra-workgroup split-K) via NND_SPLIT_CFG, next to the picker's own choice.
+    python scripts/sweep_split.py H W [B]        (on the GPU box; one subprocess per configuration)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+from nndepth_amd import weightgen
+from nndepth_amd.blocks import BasicUpdateBlock
+H, W, B = int(os.environ["AB_H"]), int(os.environ["AB_W"]), int(os.environ["AB_B"])
+ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic="bf16x3")
+weightgen.fill_module_(ub, "update_block.")
+ub = ub.to("cuda:0"); eng = ub.sync_engine("cuda:0")
+ws = eng.workspace(B, H, W, "cuda:0"); ws.normal_()
+out = []
+for i, nm in enumerate(eng.conv_names()):
+    if nm in ("encoder.convc1", "mask.2"):
+        continue
+    try:
+        ms, fl = eng.profile_conv(i, B, H, W, 20, "cuda:0")
+        out.append(f"{ms*1e3:7.1f}")
+    except Exception as e:
+        out.append("    n/a")
+print(" ".join(out), flush=True)
+''' % ROOT
+
+if __name__ == "__main__":
+    H, W = int(sys.argv[1]), int(sys.argv[2])
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    print(f"{H}x{W} batch {B}; columns: convc2 convf2 conv zr1 q1 zr2 q2 fhm   (us per launch)")
+    for cfg in [None, "1,1", "1,2", "1,4", "2,1", "2,2", "2,4", "3,1", "3,2", "3,4", "4,1", "4,2", "4,4", "6,1", "6,2", "6,4"]:
+        env = dict(os.environ, AB_H=str(H), AB_W=str(W), AB_B=str(B))
+        if cfg:
+            env["NND_SPLIT_CFG"] = cfg
+        r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.strip() and "amdgpu" not in l]
+        print(f"{cfg or 'picker':8s} {line[-1] if line else 'failed: ' + r.stderr[-200:]}", flush=True)
