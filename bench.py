@@ -29,6 +29,15 @@ sys.path.insert(0, ROOT)
 
 H_IMG, W_IMG, ITERS = 544, 960, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+DTYPE = {"fp32": "f32", "bf16x3": "f32 carried as 3 bf16 pieces per operand (6 MFMA products, fp32 accumulate)"}
+ARITH_NOTE = {
+    "fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every convolution",
+    "bf16x3": "update-block convs except convc1 / mask.2: x = x0+x1+x2, w = w0+w1+w2 in bf16, the 6 products x_i*w_j (i+j<=2) on "
+              "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-24|x||w|); encoder, correlation, lookup, "
+              "convc1, mask.2 + upsample: exact fp32; per-op error vs float64 is BELOW the exact fp32-MFMA kernel's "
+              "(tests/test_gpu_split.py); selectable: --arithmetic fp32"}
+SPLIT_PRODUCTS = {"fp32": 1, "bf16x3": 6}
 # algorithmic work of one pair: 32 x 43.15 GFLOP loop + 0.5 GFLOP pyramid + 155.2 GFLOP encoder + cnet_proj
 E2E_TFLOP = (32 * 43.15 + 0.5 + 155.2) / 1e3
 
@@ -57,6 +66,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hbm-group", action="store_true")
+    ap.add_argument("--arithmetic", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="MFMA arithmetic of the update-block convolutions: bf16x3 = fp32 operands carried as 3 bf16 pieces, 6 "
+                         "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/conv_split.hip; parity-gated, default); "
+                         "fp32 = exact fp32 MFMA (csrc/conv_mfma.hip)")
     ap.add_argument("--config", default="raft544", choices=["raft544", "kitti64", "cre8"],
                     help="raft544 = BASELINE.json configs[1] (the headline, default); kitti64 = configs[3]: 64 KITTI-size pairs "
                          "sharded over the ranks; cre8 = configs[4]: 8 CREStereo 1080x1920 pairs, 2-stage cascade, sharded")
@@ -75,7 +88,7 @@ def main():
     torch.cuda.set_device(dev)
 
     # spec of BaseRAFTStereo(context_dim=64) without touching oracle/: keys+shapes from the module itself
-    model = BaseRAFTStereo(iters=ITERS, context_dim=64)
+    model = BaseRAFTStereo(iters=ITERS, context_dim=64, arithmetic=args.arithmetic)
     weightgen.fill_module_(model)
     model = model.to(dev).eval()
     f1, f2 = weightgen.synthetic_frames(100 + rank, 1, H_IMG, W_IMG)  # a different pair per rank
@@ -124,11 +137,30 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": DTYPE[args.arithmetic],
         "data": "synthetic",
         "config": {"workload": "RAFT-Stereo base (ctx 64), 544x960, 32 iters, batch 1 per GPU, all 32 up_disp emitted",
-                   "pairs_per_step": world, "parallelism": f"batch-parallel x{world}" if world > 1 else "single"},
+                   "pairs_per_step": world, "parallelism": f"batch-parallel x{world}" if world > 1 else "single",
+                   "arithmetic": ARITH_NOTE[args.arithmetic]},
     }
+    if args.arithmetic != "fp32" and rank == 0 and world == 1:
+        # the same pair through the exact fp32-MFMA path, same run: what the split arithmetic buys and what it changes
+        exact = BaseRAFTStereo(iters=ITERS, context_dim=64, arithmetic="fp32")
+        exact.load_state_dict(model.state_dict())
+        exact = exact.to(dev).eval()
+        for _ in range(2):
+            ex_out = exact(f1, f2)
+        torch.cuda.synchronize(dev)
+        n_ex = max(5, min(20, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(n_ex):
+            ex_out = exact(f1, f2)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t1) / n_ex
+        result["exact_fp32_path"] = {
+            "value": 1.0 / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": n_ex, "dtype": DTYPE["fp32"],
+            "max_abs_up_disp_vs_this_run": float((ex_out[-1]["up_disp"] - out[-1]["up_disp"]).abs().max())}
+        del exact, ex_out
 
     # ------------------------------------------------------------------ roofline (dominant kernel)
     if not args.no_roofline and rank == 0:
@@ -159,21 +191,31 @@ def main():
             r["tflops_in_loop"] = r["gflop"] / r["ms_in_loop"]
             loop_ms += r["ms_in_loop"]
             loop_fl += r["gflop"]
+        nprod = SPLIT_PRODUCTS[args.arithmetic]  # MFMA FLOPs executed per algorithmic FLOP
+        peak = PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS
+        kern = ("conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32)" if nprod == 1 else
+                "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 6 products per fp32 product)")
         result["roofline"] = {
-            "bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2) — " + dom["conv"],
-            "achieved": dom["tflops_in_loop"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["tflops_in_loop"] / PEAK_FP32_MFMA_TFLOPS, "traffic": _traffic(),
+            "bound": "mfma", "kernel": kern + " — " + dom["conv"],
+            "achieved": nprod * dom["tflops_in_loop"], "peak": peak, "unit": "TFLOP/s",
+            "frac": nprod * dom["tflops_in_loop"] / peak, "traffic": _traffic(args.arithmetic),
+            "flops_counted": "MFMA FLOPs executed = %d x algorithmic (2*B*H*W*Cout*Cin*KH*KW)" % nprod,
+            "algorithmic_tflops": dom["tflops_in_loop"],
+            "algorithmic_frac_of_fp32_mfma_peak": dom["tflops_in_loop"] / PEAK_FP32_MFMA_TFLOPS,
             "measured": "inside the fused 32-iteration loop (hipEvents around the launch on its stream, average of iterations 2..32)",
             "launch_ms": dom["ms_in_loop"], "launch_gflop": dom["gflop"],
-            "standalone": {"launch_ms": dom["ms"], "achieved": dom["tflops"], "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS},
+            "standalone": {"launch_ms": dom["ms"], "algorithmic_tflops": dom["tflops"], "achieved": nprod * dom["tflops"],
+                           "frac": nprod * dom["tflops"] / peak},
+            # aggregates in ALGORITHMIC TFLOP/s, as a fraction of the exact-fp32 MFMA ceiling the path used to sit under
             "all_convs": {"ms_per_iter": tot_ms, "gflop_per_iter": tot_fl / 1e9,
                           "tflops": tot_fl / tot_ms / 1e9, "frac": tot_fl / tot_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
-                          "measured": "stand-alone launches"},
+                          "measured": "stand-alone launches; algorithmic FLOPs vs the 157.3 TFLOP/s fp32-MFMA peak"},
             "loop_convs": {"ms_per_iter": loop_ms, "gflop_per_iter": loop_fl,
                            "tflops": loop_fl / loop_ms, "frac": loop_fl / loop_ms / PEAK_FP32_MFMA_TFLOPS,
-                           "measured": "the 7 stand-alone conv launches of the recurrence, in the loop"},
+                           "measured": "the 7 stand-alone conv launches of the recurrence, in the loop; algorithmic FLOPs vs 157.3"},
             "end_to_end": {"tflop_per_pair": E2E_TFLOP, "tflops": E2E_TFLOP / (elapsed / args.steps),
-                           "frac": E2E_TFLOP / (elapsed / args.steps) / PEAK_FP32_MFMA_TFLOPS},
+                           "frac": E2E_TFLOP / (elapsed / args.steps) / PEAK_FP32_MFMA_TFLOPS,
+                           "measured": "algorithmic FLOPs of the whole pair / step time vs 157.3"},
             "per_conv": rows,
         }
         if not args.no_hbm_group:
@@ -298,12 +340,13 @@ def sharded_config(args):
         dist.destroy_process_group()
 
 
-def _traffic():
+def _traffic(arithmetic="fp32"):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/), else None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("dominant_kernel_hbm_bytes_per_launch")
+            d = json.load(open(p))
+            return d.get("dominant_kernel_hbm_bytes_per_launch_" + arithmetic, d.get("dominant_kernel_hbm_bytes_per_launch") if arithmetic == "fp32" else None)
         except Exception:
             return None
     return None

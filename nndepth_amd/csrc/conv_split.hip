@@ -41,11 +41,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef NND_SPLIT_AD
 #define NND_SPLIT_AD 1      // steps of lookahead of the weight-fragment stream
 #endif
-#ifndef NND_SPLIT_SPREAD
-#define NND_SPLIT_SPREAD 0  // 1: spread the staging of the next super-chunk over the MFMA steps of the current one
-#endif
 #ifndef NND_SPLIT_BSLOTS
-#define NND_SPLIT_BSLOTS 3  // register sets of the activation fragments (lookahead = sets - 1 units of 6 MFMAs)
+#define NND_SPLIT_BSLOTS 2  // register sets of the activation fragments (lookahead = sets - 1 units of 6 MFMAs); 3 measured equal, spills
 #endif
 
 #ifdef NND_DBG_STAMPS
@@ -58,8 +55,17 @@ __device__ unsigned long long g_split_stamps[4096 * 8];
             if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();        \
         }                                                                                              \
     } while (0)
+// shader-clock stamps (s_memtime) in slots 5 / 6 next to the real-time stamps 1 / 2: in-kernel clock of the K loop
+#define NND_SCLOCK(i)                                                                                  \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
+            if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memtime();            \
+        }                                                                                              \
+    } while (0)
 #else
 #define NND_SSTAMP(i)
+#define NND_SCLOCK(i)
 #endif
 
 __host__ __device__ constexpr int split_pos_bytes(int NS) { return NS * 32 + 16; }
@@ -173,7 +179,6 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
         }
     };
     // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_unit.
-    // Staging is per unit so that the chunk loop can spread it between its MFMA steps (NND_SPLIT_SPREAD).
     auto load_unit = [&](int K, int i) {
         const float* src;
         int climit;
@@ -229,11 +234,12 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
     store_x(0);
     __syncthreads();
     NND_SSTAMP(1);
+    NND_SCLOCK(5);
 
     auto chunk = [&](int K, auto par_c) {
         constexpr int par = decltype(par_c)::value;
         const bool more = (K + 1 < nsuper);
-#if !defined(NND_SPLIT_NO_STAGE) && !NND_SPLIT_SPREAD
+#ifndef NND_SPLIT_NO_STAGE
         if (more) load_x(K + 1);
 #endif
         const uint4* wc = a_ptr(K);
@@ -263,17 +269,6 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
 #else
             for (int s = 0; s < NS; ++s) an[s] = ac[s];
 #endif
-#if !defined(NND_SPLIT_NO_STAGE) && NND_SPLIT_SPREAD
-            // staging of the next super-chunk spread over this chunk's steps: unit i's loads go out at step i, its split +
-            // LDS stores run at step NT - NU + i (between MFMAs instead of in a VALU-only phase before the barrier)
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    if (t == (i < NT ? i : NT - 1)) load_unit(K + 1, i);
-                    if (NT > NU && t == NT - NU + i) store_unit(K + 1, i);
-                }
-            }
-#endif
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 const int u = t * P + pp;
@@ -296,7 +291,7 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
             }
         }
 #ifndef NND_SPLIT_NO_STAGE
-        if (more && (!NND_SPLIT_SPREAD || NT <= NU)) store_x(K + 1);
+        if (more) store_x(K + 1);
 #endif
         __syncthreads();
     };
@@ -320,6 +315,7 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
     }
 
     NND_SSTAMP(2);
+    NND_SCLOCK(6);
     // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier); slice kj then
     // owns registers [kj*16/ks, (kj+1)*16/ks) of the tile for the epilogue
     float* red_all = reinterpret_cast<float*>(lds_raw);

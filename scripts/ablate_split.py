@@ -32,12 +32,15 @@ for i, nm in enumerate(names):
         eng.profile_conv(i, 1, H, W, 1, "cuda:0")
         torch.cuda.synchronize()
         assert raw.nnd_debug_read_split_stamps(buf, 4096 * 8) == 0
-        a = np.array(buf[:], dtype=np.int64).reshape(4096, 8)[:, :5]
-        a = a[(a[:, 0] > 0) & (a[:, 4] >= a[:, 0])]
+        full = np.array(buf[:], dtype=np.int64).reshape(4096, 8)
+        keep = (full[:, 0] > 0) & (full[:, 4] >= full[:, 0])
+        a = full[keep][:, :5]
+        clk = full[keep]
+        ghz = np.median((clk[:, 6] - clk[:, 5]) / np.maximum(clk[:, 2] - clk[:, 1], 1) * 0.1)  # cycles per 10 ns -> GHz
         us = (a - a[:, 0].min()) / 100.0
         ph = np.diff(us, axis=1)
         line += (f" | WGs {len(a):4d} start spread {us[:,0].max():5.1f} | prologue {ph[:,0].mean():5.1f} K-loop {ph[:,1].mean():6.1f} "
-                 f"reduce {ph[:,2].mean():4.1f} epilogue {ph[:,3].mean():5.1f} | last end {us[:,4].max():6.1f}")
+                 f"reduce {ph[:,2].mean():4.1f} epilogue {ph[:,3].mean():5.1f} | last end {us[:,4].max():6.1f} | K-loop clock {ghz:4.2f} GHz")
     print(line, flush=True)
 ''' % ROOT
 
