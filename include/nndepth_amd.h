@@ -196,6 +196,22 @@ int nnd_conv2d_pack_ex(const float* w_host, const float* b_host, int Cout, int C
 int nnd_conv2d_forward_ex(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
                           int Cout, int KH, int KW, int relu, int arithmetic, void* stream);
 
+/* conv + CREStereo's search-offset activation in the epilogue: y = range * (sigmoid(conv(x)) - 0.5) * 2
+ *   nndepth/models/cre_stereo/model.py:158-159,171-172 (conv_offset_16 / conv_offset_8); blob of nnd_conv2d_pack.      */
+int nnd_conv2d_offset_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
+                              int Cout, int KH, int KW, float range, void* stream);
+
+/* ------------------------------------------------------------- glue operators of the model forwards (csrc/cascade.hip)
+ * nnd_split_tanh_relu    : x (B, Cnet+Cinp, H, W) -> net = tanh(x[:, :Cnet]), inp = relu(x[:, Cnet:])
+ *                          nndepth/models/raft_stereo/model.py:119-122 (igev_stereo/model.py:129-131, cre_stereo/model.py:148-151)
+ * nnd_avg_pool_2x_4x     : out2 = F.avg_pool2d(x, 2, stride=2) (N,C,H/2,W/2) and out4 = F.avg_pool2d(x, 4, stride=4)
+ *                          (N,C,H/4,W/4) in one pass                           cre_stereo/model.py:154-177
+ * nnd_resize_bilinear_ac : y (N,C,H,W) = mul * F.interpolate(x (N,C,h,w), (H,W), mode="bilinear", align_corners=True)
+ *                          cre_stereo/model.py:205-212,235-241,259-265 (flow hand-over between cascade stages)        */
+int nnd_split_tanh_relu(const float* x, float* net, float* inp, int B, int Cnet, int Cinp, int H, int W, void* stream);
+int nnd_avg_pool_2x_4x(const float* x, float* out2, float* out4, int N, int C, int H, int W, void* stream);
+int nnd_resize_bilinear_ac(const float* x, float* y, int N, int C, int h, int w, int H, int W, float mul, void* stream);
+
 /* Convolution + folded eval-mode BatchNorm + ReLU / residual epilogue (the building block of the encoder):
  *   y = conv(x; w, stride, "same" padding K/2) ; y = (y + bias - mean) * gamma / sqrt(var + eps) + beta   [norm optional]
  *   if relu: y = max(y, 0);  if residual: y = residual + y;  if relu_after_residual: y = max(y, 0)
@@ -225,6 +241,8 @@ int nnd_conv_forward(const nnd_conv_desc* desc, const float* packed_dev, const f
  * workspace: nnd_encoder_workspace_floats(desc, N, H, W) floats, caller-owned.                                     */
 typedef struct nnd_encoder_desc {
     int output_dim, norm, cnet_dim;
+    int arithmetic; /* 0 = exact fp32 MFMA; 3 = the stride-1 3x3 convolutions (and cnet_proj) on the bf16 MFMA with 3-piece
+                       split operands (see nnd_update_block_desc.arithmetic); stem, stride-2 and 1x1 layers stay fp32 */
 } nnd_encoder_desc;
 int nnd_encoder_num_tensors(const nnd_encoder_desc* desc);
 int64_t nnd_encoder_packed_floats(const nnd_encoder_desc* desc);

@@ -29,7 +29,7 @@ class Conv3dDesc(C.Structure):
 
 
 class EncoderDesc(C.Structure):
-    _fields_ = [("output_dim", C.c_int32), ("norm", C.c_int32), ("cnet_dim", C.c_int32)]
+    _fields_ = [("output_dim", C.c_int32), ("norm", C.c_int32), ("cnet_dim", C.c_int32), ("arithmetic", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/nndepth_amd.h one to one
@@ -62,6 +62,10 @@ SIGNATURES = {
     "nnd_conv2d_packed_floats_ex": (C.c_int64, [_I, _I, _I, _I, _I]),
     "nnd_conv2d_pack_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_conv2d_forward_ex": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_conv2d_offset_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.c_float, _P]),
+    "nnd_split_tanh_relu": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_avg_pool_2x_4x": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "nnd_resize_bilinear_ac": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _P]),
     "nnd_mask_upsample_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_raft_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),

@@ -166,13 +166,22 @@ class CREStereoBase(nn.Module):
             v = (tuple((t.data_ptr(), t._version) for t in tensors), str(frame1.device))
             if v != self._enc_version:
                 if self._enc_engine is None:
-                    self._enc_engine = ops.EncoderEngine(self.fnet.conv2.out_channels, self.fnet.norm_fn, 0)
+                    self._enc_engine = ops.EncoderEngine(self.fnet.conv2.out_channels, self.fnet.norm_fn, 0, self.arithmetic)
                 self._enc_engine.load(self.fnet.state_dict(), None, device=frame1.device)
                 self._enc_version = v
             B = frame1.shape[0]
             fmaps, _ = self._enc_engine.forward(torch.cat([frame1, frame2], 0).float())
             return fmaps[:B], fmaps[B:]
         return self.fnet([frame1, frame2])  # explicit opt-in (hip_encoder=False): PyTorch-ROCm modules
+
+    def _offset_convs(self, device):
+        """conv_offset_16 / conv_offset_8 packed for the MFMA conv (repacked when their parameters change)."""
+        mods = (self.conv_offset_16, self.conv_offset_8)
+        v = (tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters()), str(device))
+        if getattr(self, "_off_version", None) != v:
+            self._off_engines = tuple(ops.Conv2d(m.weight, m.bias, device=device) for m in mods)
+            self._off_version = v
+        return self._off_engines
 
     def _stage(self, corr_fn, net, inp, flow, offset, n_iters: int, iter_mode: bool, outs: List[Dict[str, torch.Tensor]]):
         if self.fused_loop and isinstance(corr_fn, AGCL) and n_iters > 0:
@@ -203,17 +212,20 @@ class CREStereoBase(nn.Module):
         hd, ds = self.hidden_dim, self.fnet_ds
         fmap1, fmap2 = self.forward_fnet(frame1, frame2)
         fmap1, fmap2 = fmap1.float(), fmap2.float()
-        net, inp = torch.split(fmap1, [hd, hd], dim=1)
-        net, inp = torch.tanh(net), F.relu(inp)
+        net, inp = ops.split_tanh_relu(fmap1, hd)  # split + tanh + relu in one kernel (model.py:148-151)
         outs: List[Dict[str, torch.Tensor]] = []
         if flow_init is not None:
             scale = fmap1.shape[2] / flow_init.shape[2]
-            flow = -scale * F.interpolate(flow_init, size=fmap1.shape[2:], mode="bilinear", align_corners=True)
+            flow = ops.resize_bilinear_ac(flow_init.float(), fmap1.shape[2:], -scale)
         else:
+            # both pooled scales of every map in one pass each (model.py:154-177)
+            f1_8, f1_16 = ops.avg_pool_2x_4x(fmap1)
+            f2_8, f2_16 = ops.avg_pool_2x_4x(fmap2)
+            net8, net16 = ops.avg_pool_2x_4x(net)
+            inp8, inp16 = ops.avg_pool_2x_4x(inp)
+            conv16, conv8 = self._offset_convs(fmap1.device)
             # 1/(4*ds): attention-refined features, learned offsets, cross attention inside every AGCL call
-            f1_16, f2_16 = F.avg_pool2d(fmap1, 4, stride=4), F.avg_pool2d(fmap2, 4, stride=4)
-            off16 = self.range_16 * (torch.sigmoid(self.conv_offset_16(f1_16)) - 0.5) * 2.0
-            net16, inp16 = F.avg_pool2d(net, 4, stride=4), F.avg_pool2d(inp, 4, stride=4)
+            off16 = ops.conv2d_offset(conv16, f1_16, self.range_16)  # range * (sigmoid(conv) - 0.5) * 2 in the conv epilogue
             n, c, h16, w16 = f1_16.shape
             pe = position_encoding_sine(c, frame1.shape[2] // (ds * 4), frame1.shape[3] // (ds * 4), f1_16.device)
             pe = pe[:, :, :h16, :w16]
@@ -222,14 +234,12 @@ class CREStereoBase(nn.Module):
             _, _, up = self._stage(self.corr_cls(f1_16, f2_16, att=self.cross_att_fn), net16, inp16, flow16, off16,
                                    self.iters // 2, False, outs)
             # 1/(2*ds): learned offsets, no attention
-            f1_8, f2_8 = F.avg_pool2d(fmap1, 2, stride=2), F.avg_pool2d(fmap2, 2, stride=2)
-            off8 = self.range_8 * (torch.sigmoid(self.conv_offset_8(f1_8)) - 0.5) * 2.0
-            net8, inp8 = F.avg_pool2d(net, 2, stride=2), F.avg_pool2d(inp, 2, stride=2)
+            off8 = ops.conv2d_offset(conv8, f1_8, self.range_8)
             scale = f1_8.shape[2] / up.shape[2]
-            flow8 = scale * F.interpolate(up, size=f1_8.shape[2:], mode="bilinear", align_corners=True)
+            flow8 = ops.resize_bilinear_ac(up, f1_8.shape[2:], scale)  # scale * interpolate(bilinear, align_corners=True)
             _, _, up = self._stage(self.corr_cls(f1_8, f2_8), net8, inp8, flow8, off8, self.iters // 2, False, outs)
             scale = fmap1.shape[2] / up.shape[2]
-            flow = scale * F.interpolate(up, size=fmap1.shape[2:], mode="bilinear", align_corners=True)
+            flow = ops.resize_bilinear_ac(up, fmap1.shape[2:], scale)
         # 1/ds: plain warped window correlation
         _, _, up = self._stage(self.corr_cls(fmap1, fmap2), net, inp, flow, None, self.iters, True, outs)
         if self.test_mode:
@@ -243,7 +253,7 @@ def two_stage_forward(model: CREStereoBase, frame1: torch.Tensor, frame2: torch.
     full-resolution pair with `flow_init` = the half-resolution result (one stage of `iters` iterations at 1/8)."""
     # half resolution, rounded up to a multiple of 32 (the cascade needs H/32 == (H/8)//4: model.py:172-174)
     h, w = -(-(frame1.shape[2] // 2) // 32) * 32, -(-(frame1.shape[3] // 2) // 32) * 32
-    small = [F.interpolate(f, size=(h, w), mode="bilinear", align_corners=True) for f in (frame1, frame2)]
+    small = [ops.resize_bilinear_ac(f.float(), (h, w)) for f in (frame1, frame2)]  # interpolate(bilinear, align_corners=True)
     coarse = model(small[0], small[1])
     init = coarse if torch.is_tensor(coarse) else coarse[-1]["up_disp"]
     return model(frame1, frame2, flow_init=init)

@@ -48,8 +48,9 @@ enum ConvEpilogue {
                      // co >= hidden: out1[co-hidden] = sigmoid(v) * aux0  (r*h)
     EPI_GRU_Q = 3,   // q = tanh(v); out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z); out1 (optional) = copy
     EPI_SCALE = 4,   // out0 = scale * v
-    EPI_AFFINE = 5   // y = acc * cscale[co] + shift[co] (folded norm; shift in the bias slot); flags bit 0: ReLU;
+    EPI_AFFINE = 5,  // y = acc * cscale[co] + shift[co] (folded norm; shift in the bias slot); flags bit 0: ReLU;
                      // aux0 (optional): y = aux0 + y; flags bit 1: ReLU          (encoder / residual blocks)
+    EPI_SIGMOID_RANGE = 6  // out0 = scale * (sigmoid(v) - 0.5) * 2    (CREStereo's learned search offsets, cre_stereo/model.py:158-159)
 };
 
 // One convolution layer inside a packed parameter blob.

@@ -130,6 +130,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
                 a.out0[b * a.obs0 + co * DP + pix] = v;
             } else if (epi == EPI_SCALE) {
                 a.out0[b * a.obs0 + co * DP + pix] = a.scale * v;
+            } else if (epi == EPI_SIGMOID_RANGE) {
+                a.out0[b * a.obs0 + co * DP + pix] = a.scale * (sigmoidf_(v) - 0.5f) * 2.0f;
             } else if (epi == EPI_AFFINE) {  // folded norm: y = acc*scale + shift; optional ReLU, residual add, ReLU
                 float y2 = fmaf(acc[pp][reg], z_r[reg], bias_r[reg]);
                 if (a.flags & 4) y2 = y2 > 0.f ? y2 : a.scale * y2;  // LeakyReLU (slope in `scale`), Conv3d path

@@ -31,7 +31,8 @@
 namespace nnd {
 
 // ------------------------------------------------------------------------------------------ generic conv + norm
-static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total) {
+// arith != 0 asks for the split-bf16 MFMA kernel (conv_split.hip); shapes it does not build fall back to the exact fp32 kernel
+static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total, int arith = 0) {
     NND_REQUIRE(d, "conv: null descriptor");
     NND_REQUIRE(d->Cout > 0 && d->Cin > 0, "conv: bad channel counts");
     NND_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d not supported (1, 2)", d->stride);
@@ -43,7 +44,10 @@ static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total) {
                     "conv: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", d->KH, d->KW);
     ConvLayer l;
     l.KH = d->KH; l.KW = d->KW; l.Cin = d->Cin; l.Cout = d->Cout; l.stride = d->stride;
-    l.CI_T = conv_ci_t(d->KH, d->KW, d->Cin, d->stride, d->Cout);
+    // the 1x1 projections stay on the streaming fp32 kernel (HBM-bound); 3x3 stride-1 layers may take the split kernel
+    if (arith != 0 && (k11 || !conv_split_supported(d->KH, d->KW, d->Cin, d->stride, arith))) arith = 0;
+    l.arith = arith;
+    l.CI_T = arith ? 16 : conv_ci_t(d->KH, d->KW, d->Cin, d->stride, d->Cout);
     l.nchunks = cdiv(d->Cin, l.CI_T);
     l.ncb = cdiv(d->Cout, 32);
     int64_t off = 0;
@@ -290,9 +294,9 @@ static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
         int64_t t;
         nnd_conv_desc a{dim, cin, 3, 3, st}, b{dim, dim, 3, 3, 1}, c{dim, cin, 1, 1, st};
         int rc;
-        if ((rc = conv_layer(&a, &p->c1[i], &t)) != NND_OK) return rc;
+        if ((rc = conv_layer(&a, &p->c1[i], &t, d->arithmetic)) != NND_OK) return rc;
         p->base1[i] = off; off += t;
-        if ((rc = conv_layer(&b, &p->c2[i], &t)) != NND_OK) return rc;
+        if ((rc = conv_layer(&b, &p->c2[i], &t, d->arithmetic)) != NND_OK) return rc;
         p->base2[i] = off; off += t;
         if ((rc = conv_layer(&c, &p->ds[i], &t)) != NND_OK) return rc;
         p->based[i] = off; off += t;
@@ -306,7 +310,7 @@ static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
     p->base_cnet = off;
     if (d->cnet_dim > 0) {
         nnd_conv_desc c{d->cnet_dim, d->output_dim, 3, 3, 1};
-        if ((rc = conv_layer(&c, &p->cnet, &t)) != NND_OK) return rc;
+        if ((rc = conv_layer(&c, &p->cnet, &t, d->arithmetic)) != NND_OK) return rc;
         off += t;
     }
     p->total = off;

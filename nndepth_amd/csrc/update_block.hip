@@ -80,7 +80,8 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->L[C_C2] = mk(3, 3, 256, 192, &off, ar(C_C2));
     p->f1_w = off; off += (int64_t)128 * fc * 49;
     p->f1_b = off; off += 128;
-    p->L[C_F2] = mk(3, 3, 128, 64, &off, ar(C_F2));
+    p->L[C_F2] = mk(3, 3, 128, 64, &off);  // side stream, beside convc2: stays on the fp32 kernel, whose small workgroups fit
+                                           // next to the one-per-CU workgroups of the split kernel (in-loop convc2 71 -> see DESIGN §4)
     p->L[C_CV] = mk(3, 3, 256, hid - fc, &off, ar(C_CV));
     for (int pass = 0; pass < (p->sep ? 2 : 1); ++pass) {
         const int kh = p->sep ? (pass == 0 ? 1 : 5) : 3, kw = p->sep ? (pass == 0 ? 5 : 1) : 3;
@@ -850,6 +851,20 @@ int nnd_conv2d_forward_ex(const float* packed_dev, const float* x, float* y, int
 int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
                        int KW, int relu, void* stream) {
     return nnd_conv2d_forward_ex(packed_dev, x, y, B, Cin, H, W, Cout, KH, KW, relu, 0, stream);
+}
+
+int nnd_conv2d_offset_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
+                              int KW, float range, void* stream) {
+    ConvLayer L;
+    int rc = conv2d_layer(Cout, Cin, KH, KW, 0, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev && x && y && B > 0 && H > 0 && W > 0, "conv2d_offset_forward: bad argument");
+    const int64_t n = (int64_t)H * W;
+    ConvIO io{};
+    io.src0 = act(const_cast<float*>(x), Cin * n, Cin);
+    io.out0 = act(y, Cout * n, Cout);
+    io.scale = range;
+    return launch_conv(L, packed_dev, io, EPI_SIGMOID_RANGE, B, H, W, (hipStream_t)stream);
 }
 
 int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,

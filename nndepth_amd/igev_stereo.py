@@ -215,8 +215,7 @@ class IGEVStereoBase(nn.Module):
         fmap1, fmap2, cnet1, guide_features = self.forward_fnet(frame1, frame2)
         fnet_ds = frame1.shape[-1] // fmap1.shape[-1]
         fmap1, fmap2 = fmap1.float(), fmap2.float()
-        net, inp = torch.split(cnet1, cnet1.shape[1] // 2, dim=1)
-        net, inp = torch.tanh(net), F.relu(inp)
+        net, inp = ops.split_tanh_relu(cnet1.float(), cnet1.shape[1] // 2)  # split + tanh + relu in one kernel (model.py:129-131)
         corr = self.corr_fn(fmap1, fmap2, guide_features, self.cv_regularizer, self.corr_levels, self.corr_radius,
                             self.cv_groups)
         B, _, H1, W1 = fmap1.shape

@@ -113,6 +113,60 @@ class Conv2d:
         return y
 
 
+def conv2d_offset(conv: "Conv2d", x: torch.Tensor, rng: float) -> torch.Tensor:
+    """rng * (sigmoid(conv(x)) - 0.5) * 2 in the conv's epilogue (CREStereo search offsets, cre_stereo/model.py:158-159)."""
+    d = _dev(x, conv.packed)
+    if conv.arith != 0:
+        raise NndError("conv2d_offset: exact fp32 packing expected")
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    if Cin != conv.Cin:
+        raise NndError(f"conv2d_offset: input has {Cin} channels, weights expect {conv.Cin}")
+    y = torch.empty((B, conv.Cout, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_conv2d_offset_forward(_p(conv.packed), _p(x), _p(y), B, Cin, H, W, conv.Cout, conv.KH, conv.KW, float(rng),
+                                            _stream(d)), "conv2d_offset_forward")
+    return y
+
+
+def split_tanh_relu(x: torch.Tensor, c_net: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """net = tanh(x[:, :c_net]), inp = relu(x[:, c_net:]) in one kernel (raft_stereo/model.py:119-122)."""
+    d = _dev(x)
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    if not 0 < c_net < Cc:
+        raise NndError(f"split_tanh_relu: cannot split {Cc} channels at {c_net}")
+    net = torch.empty((B, c_net, H, W), dtype=torch.float32, device=d)
+    inp = torch.empty((B, Cc - c_net, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_split_tanh_relu(_p(x), _p(net), _p(inp), B, c_net, Cc - c_net, H, W, _stream(d)), "split_tanh_relu")
+    return net, inp
+
+
+def avg_pool_2x_4x(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(F.avg_pool2d(x, 2, stride=2), F.avg_pool2d(x, 4, stride=4)) in one pass (cre_stereo/model.py:154-177)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    o2 = torch.empty((N, Cc, H // 2, W // 2), dtype=torch.float32, device=d)
+    o4 = torch.empty((N, Cc, H // 4, W // 4), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_avg_pool_2x_4x(_p(x), _p(o2), _p(o4), N, Cc, H, W, _stream(d)), "avg_pool_2x_4x")
+    return o2, o4
+
+
+def resize_bilinear_ac(x: torch.Tensor, size: Tuple[int, int], mul: float = 1.0) -> torch.Tensor:
+    """mul * F.interpolate(x, size, mode="bilinear", align_corners=True) (cre_stereo/model.py:235-241)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Cc, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_resize_bilinear_ac(_p(x), _p(y), N, Cc, h, w, H, W, float(mul), _stream(d)), "resize_bilinear_ac")
+    return y
+
+
 def mask_upsample(conv: "Conv2d", x: torch.Tensor, flow: torch.Tensor, rate: int) -> torch.Tensor:
     """convex_upsample(flow, 0.25 * conv1x1(x)) in one kernel; `conv` = Conv2d packed from mask.2's (9r^2,Cin,1,1)."""
     d = _dev(x, flow, conv.packed)
@@ -506,11 +560,12 @@ class EncoderEngine:
     layer1.0.conv1.weight, layer1.0.downsample.0.weight, layer1.0.norm3.weight, ..., conv2.bias) and, optionally,
     `cnet_sd` with `0.weight` / `0.bias` of the cnet_proj Sequential."""
 
-    def __init__(self, output_dim: int, norm: str = "batch", cnet_dim: int = 0):
+    def __init__(self, output_dim: int, norm: str = "batch", cnet_dim: int = 0, arithmetic: str = "fp32"):
         if norm not in ("batch", "none", "instance"):
             raise NndError(f"EncoderEngine: norm_fn '{norm}' is not built in HIP (batch in eval mode, instance, none)")
         self.norm = norm
-        self.desc = EncoderDesc(int(output_dim), {"none": 0, "batch": 1, "instance": 2}[norm], int(cnet_dim))
+        self.desc = EncoderDesc(int(output_dim), {"none": 0, "batch": 1, "instance": 2}[norm], int(cnet_dim),
+                                UpdateBlockEngine.ARITHMETIC[arithmetic])
         n = int(lib.nnd_encoder_packed_floats(C.byref(self.desc)))
         if n <= 0:
             check(n, "encoder_packed_floats")

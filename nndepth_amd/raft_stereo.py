@@ -97,7 +97,8 @@ class BaseRAFTStereo(nn.Module):
         v = (tuple((t.data_ptr(), t._version) for t in tensors), str(device))
         if v != self._enc_version:
             if self._enc_engine is None:
-                self._enc_engine = ops.EncoderEngine(self.fnet_dim, self.fnet.norm_fn, self.context_dim + self.hidden_dim)
+                self._enc_engine = ops.EncoderEngine(self.fnet_dim, self.fnet.norm_fn, self.context_dim + self.hidden_dim,
+                                                     self.arithmetic)
             self._enc_engine.load(self.fnet.state_dict(), self.cnet_proj.state_dict(), eps=1e-5, device=device)
             self._enc_version = v
         return self._enc_engine
@@ -124,8 +125,7 @@ class BaseRAFTStereo(nn.Module):
         fmap1, fmap2, cnet = self.forward_fnet(frame1, frame2)
         rate = frame1.shape[-1] // fmap1.shape[-1]
         fmap1, fmap2 = fmap1.float(), fmap2.float()
-        net, inp = torch.split(cnet, [self.hidden_dim, self.context_dim], dim=1)
-        net, inp = torch.tanh(net), torch.relu(inp)
+        net, inp = ops.split_tanh_relu(cnet.float(), self.hidden_dim)  # split + tanh + relu in one kernel (model.py:119-122)
         corr = self.corr_fn(fmap1, fmap2, self.corr_levels, self.corr_radius)
         if self.fused_loop and isinstance(corr, CorrBlock1D):
             eng = self.update_block.sync_engine(frame1.device)

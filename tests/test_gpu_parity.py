@@ -742,6 +742,37 @@ def test_cre_cascade_midsize_vs_oracle(cre_sd, CR):
     assert max(errs) <= 1e-4
 
 
+def test_cascade_glue_ops_vs_torch(ops):
+    """The small operators between the big kernels (csrc/cascade.hip + the sigmoid-range conv epilogue) against the PyTorch
+    ops the reference uses at those places: cre_stereo/model.py:148-177,205-212,235-265, raft_stereo/model.py:119-122."""
+    F = torch.nn.functional
+    torch.manual_seed(31)
+    # split + tanh + relu
+    x = torch.randn(2, 192, 17, 30) * 2
+    net, inp = ops.split_tanh_relu(x.to(DEV), 128)
+    assert (net.cpu() - torch.tanh(x[:, :128])).abs().max() <= 3e-7 and torch.equal(inp.cpu(), torch.relu(x[:, 128:]))
+    # 2x and 4x average pools in one pass, incl. odd sizes (135x240 -> 67x120 -> 33x60 is CREStereo at 1080x1920)
+    for (N, C, H, W) in ((1, 8, 135, 240), (2, 3, 9, 14), (1, 2, 4, 4), (1, 4, 34, 60)):
+        x = torch.randn(N, C, H, W)
+        o2, o4 = ops.avg_pool_2x_4x(x.to(DEV))
+        assert (o2.cpu() - F.avg_pool2d(x, 2, stride=2)).abs().max() <= 2e-7, (N, C, H, W)
+        assert (o4.cpu() - F.avg_pool2d(x, 4, stride=4)).abs().max() <= 3e-7, (N, C, H, W)
+    # scale * bilinear resize with align_corners=True (flow hand-over between the cascade stages, both directions)
+    for (h, w, H, W, mul) in ((33, 60, 67, 120, 67 / 33), (67, 120, 135, 240, 135 / 67), (544, 960, 68, 120, -0.125), (5, 7, 5, 7, 1.0),
+                              (1, 9, 4, 3, 2.0)):
+        x = torch.randn(2, 2, h, w) * 10
+        got = ops.resize_bilinear_ac(x.to(DEV), (H, W), mul).cpu()
+        exp = mul * F.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
+        assert (got - exp).abs().max() <= 2e-5, (h, w, H, W, float((got - exp).abs().max()))
+    # conv_offset: range * (sigmoid(conv3x3(x)) - 0.5) * 2 in the conv epilogue
+    conv = torch.nn.Conv2d(256, 18, 3, padding=1)
+    x = torch.randn(1, 256, 33, 60)
+    with torch.no_grad():
+        exp = 1.0 * (torch.sigmoid(conv(x)) - 0.5) * 2.0
+    got = ops.conv2d_offset(ops.Conv2d(conv.weight, conv.bias), x.to(DEV), 1.0).cpu()
+    assert (got - exp).abs().max() <= 2e-6
+
+
 # ------------------------------------------------------------ IGEV model (a15 in PyTorch, a16 init + loop in HIP)
 def test_igev_softargmin_vs_oracle(ops, R):
     torch.manual_seed(12)

@@ -122,3 +122,56 @@ def test_forward_small_golden_bf16x3(gold, raft_sd):
     out = m.to(DEV).eval()(f1.to(DEV), f2.to(DEV))
     for i in range(6):
         assert np.abs(out[i]["up_disp"].cpu().numpy() - g["up_disp"][i]).max() <= 1e-4, i
+
+
+def test_encoder_fullsize_bf16x3_vs_oracle(raft_sd, tartanair_frames):
+    """f-1 with arithmetic bf16x3: the encoder's stride-1 3x3 convolutions and cnet_proj on the split kernel (stem, stride-2
+    and 1x1 layers exact fp32) at 544x960 against the oracle's encoder: same bound as the exact path (<= 5e-5)."""
+    from oracle import torch_ref as R
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    m = BaseRAFTStereo(iters=1, context_dim=64, arithmetic="bf16x3")
+    m.load_state_dict(raft_sd, strict=True)
+    m = m.to(DEV).eval()
+    f1, f2 = tartanair_frames
+    fm1, fm2, cnet = m.forward_fnet(f1.to(DEV), f2.to(DEV))
+    with torch.no_grad():
+        ref = R.basic_encoder(raft_sd, "fnet", torch.cat([f1, f2], 0))
+        ref_c = torch.relu(R._conv(raft_sd, "cnet_proj.0", ref[:1], padding=1))
+    e1 = (torch.cat([fm1, fm2]).cpu() - ref).abs().max().item()
+    e2 = (cnet.cpu() - ref_c).abs().max().item()
+    print(f"\nencoder bf16x3 544x960: fmap max-abs {e1:.2e} (|fmap| max {ref.abs().max():.2f}), cnet {e2:.2e}")
+    assert e1 <= 5e-5 and e2 <= 5e-5
+
+
+def test_cre_cascade_small_golden_bf16x3(gold, cre_sd):
+    """a20 with the split arithmetic: the reference's 8 cascade outputs (tests/golden/cre_forward.npz), instance-norm encoder
+    and update block on the split kernel."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cre_stereo import CREStereoBase
+    g = gold("cre_forward.npz")
+    fr1, fr2 = weightgen.synthetic_frames(3, 1, 128, 192)
+    m = CREStereoBase(iters=4, arithmetic="bf16x3")
+    m.load_state_dict(cre_sd, strict=True)
+    outs = m.to(DEV).eval()(fr1.to(DEV), fr2.to(DEV))
+    errs = [np.abs(o["up_disp"].cpu().numpy() - g[f"up_disp_{i}"]).max() for i, o in enumerate(outs)]
+    print("\ncre cascade bf16x3 max-abs per output:", " ".join(f"{e:.2e}" for e in errs))
+    assert len(outs) == 8 and max(errs) <= 1e-4
+
+
+def test_igev_forward_golden_bf16x3(gold):
+    """a16 with the split arithmetic in the loop: the reference's IGEVStereoBase outputs on the tiny backbone."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from igev_double import make_igev
+    from nndepth_amd import weightgen
+    from nndepth_amd.igev_stereo import IGEVStereoBase, CostVolumeFilterNetwork
+    g = gold("igev_forward.npz")
+    m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=4, hidden_dim=64, context_dim=64, arithmetic="bf16x3")
+    weightgen.fill_module_(m, "igev.")
+    m = m.to(DEV).eval()
+    f1, f2 = weightgen.synthetic_frames(6, 1, 128, 192)
+    outs = m(f1.to(DEV), f2.to(DEV))
+    errs = [np.abs(o["up_disp"].cpu().numpy() - g["up_disp"][i]).max() for i, o in enumerate(outs)]
+    print("\nigev forward bf16x3 max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
+    assert len(outs) == 4 and max(errs) <= 1e-4
