@@ -3,8 +3,8 @@ files = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 d = collections.OrderedDict()
 for f in files:
     for r in csv.DictReader(open(f)):
-        if "conv_mfma" not in r["Kernel_Name"]: continue
-        k = (r["Kernel_Name"][22:48], r["Grid_Size"], r["Workgroup_Size"])
+        if "conv_mfma" not in r["Kernel_Name"] and "conv_split" not in r["Kernel_Name"]: continue
+        k = (r["Kernel_Name"].replace("void nnd::", "")[:44], r["Grid_Size"], r["Workgroup_Size"])
         d.setdefault(k, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in d.items():
     m = {n: sum(x) / len(x) for n, x in v.items()}

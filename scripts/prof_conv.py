@@ -5,7 +5,8 @@ import torch
 from nndepth_amd import weightgen
 from nndepth_amd.blocks import BasicUpdateBlock
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8)
+arith = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic=arith)
 weightgen.fill_module_(ub, "update_block.")
 ub = ub.to("cuda:0")
 eng = ub.sync_engine("cuda:0")

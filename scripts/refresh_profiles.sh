@@ -10,8 +10,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python 
 python scripts/trace_summary.py $O/trace > $O/kernel_by_grid.txt
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 find $O/trace -name "*kernel_trace.csv" -delete
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python scripts/prof_conv.py 3 > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python scripts/prof_conv.py 3 > $O/pmc_write.log 2>&1
+ARITH=${NND_PROFILE_ARITH:-bf16x3}
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python scripts/prof_conv.py 3 $ARITH > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python scripts/prof_conv.py 3 $ARITH > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/pmc_sq -o s -- python scripts/prof_conv.py 3 $ARITH > $O/pmc_sq.log 2>&1 || true
+python scripts/pmc_summary.py $O/pmc_sq > $O/pmc_conv_sq.txt 2>&1 || true
 python - <<PY
 import csv, glob, collections
 d = collections.OrderedDict()
@@ -21,7 +24,7 @@ for f in glob.glob("$O/pmc_*/**/*counter_collection.csv", recursive=True):
         k = (r["Kernel_Name"].replace("void ", ""), r["Grid_Size"], r["Workgroup_Size"])
         d.setdefault(k, collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$O/pmc_conv_traffic.txt", "w") as o:
-    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python scripts/prof_conv.py 3 on MI355X\n")
+    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python scripts/prof_conv.py 3 $ARITH on MI355X\n")
     o.write("# units: KB per dispatch (averaged over the dispatches of that kernel/grid); gfx950: FETCH_SIZE counts 1/2 of a 16-B/lane coalesced stream (MI355X_MICROARCH.md HBM section)\n")
     o.write("kernel | grid | wg | FETCH_SIZE_KB | WRITE_SIZE_KB\n")
     for k, v in d.items():
@@ -29,5 +32,5 @@ with open("$O/pmc_conv_traffic.txt", "w") as o:
         o.write(f"{k[0]} | {k[1]} | {k[2]} | {m.get('FETCH_SIZE', float('nan')):.1f} | {m.get('WRITE_SIZE', float('nan')):.1f}\n")
 print(open("$O/pmc_conv_traffic.txt").read())
 PY
-find $O/pmc_fetch $O/pmc_write -name "*.csv" -size +1M -delete
+find $O/pmc_fetch $O/pmc_write $O/pmc_sq -name "*.csv" -size +1M -delete
 tail -1 $O/bench_line.json | python scripts/bench_summary.py

@@ -6,6 +6,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     m = re.search(r"conv_mfma_kernel<([^>]*)>", n)
     if m: return "conv<" + m.group(1).replace(" ", "") + ">"
+    m = re.search(r"conv_split_kernel<([^>]*)>", n)
+    if m: return "conv_split<" + m.group(1).replace(" ", "") + ">"
     m = re.search(r"(\w+_kernel)(<[^>]*>)?", n)
     return (m.group(1) + (m.group(2) or "")) if m else n[:30]
 idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
@@ -27,7 +29,7 @@ span = (int(main[-1]["End_Timestamp"]) - int(main[0]["Start_Timestamp"])) / 1e3
 print(f"main stream: span {span/1e3:.2f} ms, kernels {tot_main/1e3:.2f} ms, gaps {gaps/1e3:.2f} ms")
 
 # stand-alone launches of bench.py's roofline leg (nnd_profile_conv: 1 warm + 20 timed launches per layer, after the steps)
-tail = [r for r in rows[last + 1:] if "conv_mfma" in r["Kernel_Name"]]
+tail = [r for r in rows[last + 1:] if "conv_mfma" in r["Kernel_Name"] or "conv_split" in r["Kernel_Name"]]
 g2 = collections.OrderedDict()
 for r in tail:
     k = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Workgroup_Size_X"])

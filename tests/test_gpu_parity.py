@@ -763,7 +763,8 @@ def test_cascade_glue_ops_vs_torch(ops):
         x = torch.randn(2, 2, h, w) * 10
         got = ops.resize_bilinear_ac(x.to(DEV), (H, W), mul).cpu()
         exp = mul * F.interpolate(x, size=(H, W), mode="bilinear", align_corners=True)
-        assert (got - exp).abs().max() <= 2e-5, (h, w, H, W, float((got - exp).abs().max()))
+        # ATen evaluates the source index in a slightly different association: a few ulp of the interpolated value
+        assert (got - exp).abs().max() <= 1e-6 * max(1.0, exp.abs().max().item()), (h, w, H, W, float((got - exp).abs().max()))
     # conv_offset: range * (sigmoid(conv3x3(x)) - 0.5) * 2 in the conv epilogue
     conv = torch.nn.Conv2d(256, 18, 3, padding=1)
     x = torch.randn(1, 256, 33, 60)
