@@ -291,6 +291,8 @@ int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed_dev, con
  * nnd_conv3d_pack (HOST): w (Cout, Cin0+Cin1, 3, 3, 3), bias / bn_* may be NULL.  leaky_slope 1 = no activation.          */
 typedef struct nnd_conv3d_desc {
     int Cout, Cin0, Cin1, stride;
+    int arithmetic; /* 0 = exact fp32 MFMA; 3 = bf16 MFMA with 3-piece split operands for the stride-1 layers
+                       (see nnd_update_block_desc.arithmetic) */
 } nnd_conv3d_desc;
 int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc);
 int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w_host, const float* bias_host, const float* bn_gamma,

@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
 
 
 class Conv3dDesc(C.Structure):
-    _fields_ = [("Cout", C.c_int32), ("Cin0", C.c_int32), ("Cin1", C.c_int32), ("stride", C.c_int32)]
+    _fields_ = [("Cout", C.c_int32), ("Cin0", C.c_int32), ("Cin1", C.c_int32), ("stride", C.c_int32), ("arithmetic", C.c_int32)]
 
 
 class EncoderDesc(C.Structure):

@@ -80,6 +80,7 @@ class CostVolumeFilterNetwork(nn.Module):
         self.conv1_up = _cbr3d(2 * c, c, 1)
         self.final_conv = _cbr3d(c, c, 1)
         self.hip = True  # on the GPU at inference: Conv3d / upsample / gating in HIP (False keeps the PyTorch ops)
+        self.arithmetic = "fp32"  # "bf16x3": stride-1 Conv3d layers on the split-bf16 MFMA kernel (csrc/conv_split.hip)
         self._hip, self._hip_version = None, None
 
     def forward(self, x: torch.Tensor, features: List[torch.Tensor]) -> torch.Tensor:
@@ -101,12 +102,12 @@ class CostVolumeFilterNetwork(nn.Module):
     # ---- HIP path (csrc/conv3d.hip): the whole hourglass on depth-major volumes, every Conv3d one MFMA-conv launch per sample
     def _engines(self, device):
         tensors = list(self.state_dict().values())
-        v = (tuple((t.data_ptr(), t._version) for t in tensors), str(device))
+        v = (tuple((t.data_ptr(), t._version) for t in tensors), str(device), self.arithmetic)
         if v == self._hip_version:
             return self._hip
         def c3(m, stride=1, split=0):
             bn = (m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var)
-            return ops.Conv3dNorm(m.conv.weight, None, stride, bn, m.bn.eps, m.relu.negative_slope, split, device)
+            return ops.Conv3dNorm(m.conv.weight, None, stride, bn, m.bn.eps, m.relu.negative_slope, split, device, self.arithmetic)
         def gate(g):
             a, bnm, _, b = g.feat_att
             bn = (bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var)
@@ -171,6 +172,8 @@ class IGEVStereoBase(nn.Module):
                                              cor_planes=corr_levels * (2 * corr_radius + 1) * cv_groups * 2, spatial_scale=4,
                                              arithmetic=arithmetic)
         self.cv_regularizer = self._init_cost_volume_filter()
+        if hasattr(self.cv_regularizer, "arithmetic"):
+            self.cv_regularizer.arithmetic = arithmetic
         self.corr_fn = GeometryAwareCostVolume
         self.cv_squeezer = nn.Conv3d(cv_groups, 1, 3, 1, 1)
         self.tracing, self.include_preprocessing = tracing, include_preprocessing

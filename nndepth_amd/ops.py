@@ -752,12 +752,12 @@ class Conv3dNorm:
     channel concat of two volumes.  `bn` = (weight, bias, running_mean, running_var) or None."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, bn=None, eps: float = 1e-5,
-                 leaky_slope: float = 1.0, split: int = 0, device="cuda"):
+                 leaky_slope: float = 1.0, split: int = 0, device="cuda", arithmetic: str = "fp32"):
         Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
         if tuple(weight.shape[2:]) != (3, 3, 3):
             raise NndError("Conv3dNorm: only 3x3x3 kernels")
         cin0 = split if split > 0 else Cin
-        self.desc = Conv3dDesc(Cout, cin0, Cin - cin0, int(stride))
+        self.desc = Conv3dDesc(Cout, cin0, Cin - cin0, int(stride), UpdateBlockEngine.ARITHMETIC[arithmetic])
         self.leaky = float(leaky_slope)
         n = int(lib.nnd_conv3d_packed_floats(C.byref(self.desc)))
         if n <= 0:

@@ -4,7 +4,7 @@ r = json.loads(line)
 print(f"pairs/s {r['value']:.2f}  ms/step {r['ms_per_step']:.2f}")
 rf = r.get("roofline")
 if rf:
-    print("all convs:", {k: round(v, 3) for k, v in rf["all_convs"].items()})
+    print("all convs:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rf["all_convs"].items()})
     for c in rf["per_conv"]:
         print(f"  {c['conv']:30s} {c['ms']*1e3:8.1f} us  {c['gflop']:7.3f} GF  {c['tflops']:6.1f} TF (alg)" +
               (f"   in loop {c['ms_in_loop']*1e3:7.1f} us" if "ms_in_loop" in c else ""))

@@ -11,6 +11,7 @@ from nndepth_amd.igev_stereo import CostVolumeFilterNetwork  # noqa: E402
 
 dev = "cuda:0"
 reg = CostVolumeFilterNetwork(8, [40, 80, 160]).to(dev).eval()
+reg.arithmetic = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 weightgen.fill_module_(reg, "igev.cv_regularizer.")
 e = reg._engines(dev)
 rows = torch.randn(1, 8, 136, 240, 240, device=dev)

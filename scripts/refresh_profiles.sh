@@ -6,7 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_line.json 2> $O/bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_prof_line.json 2> $O/bench_prof.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-hbm-group > $O/bench_prof_line.json 2> $O/bench_prof.log
 python scripts/trace_summary.py $O/trace > $O/kernel_by_grid.txt
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 find $O/trace -name "*kernel_trace.csv" -delete

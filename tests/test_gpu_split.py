@@ -175,3 +175,23 @@ def test_igev_forward_golden_bf16x3(gold):
     errs = [np.abs(o["up_disp"].cpu().numpy() - g["up_disp"][i]).max() for i, o in enumerate(outs)]
     print("\nigev forward bf16x3 max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
     assert len(outs) == 4 and max(errs) <= 1e-4
+
+
+@pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
+def test_igev_regulariser_golden_bf16x3(gold, name, B, H, W):
+    """a15 with the stride-1 Conv3d layers on the split kernel: the reference's regularised volume (igev_volume.npz: geo0)."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.cost_volume import GeometryAwareCostVolume
+    from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
+    g = gold("igev_volume.npz")
+    f1, f2 = t(g[name + "_f1"]).to(DEV), t(g[name + "_f2"]).to(DEV)
+    guides = [torch.from_numpy(weightgen.uniform01(f"ig{j}" + name, B * c * (H >> (j + 1)) * (W >> (j + 1))
+                                                   ).reshape(B, c, H >> (j + 1), W >> (j + 1))).to(DEV)
+              for j, c in enumerate((40, 80, 160))]
+    reg = CostVolumeFilterNetwork(8, [40, 80, 160]).eval()
+    reg.arithmetic = "bf16x3"
+    weightgen.fill_module_(reg, "igev.cv_regularizer.")
+    cv = GeometryAwareCostVolume(f1, f2, guides, reg.to(DEV), 4, 4, 8)
+    err = np.abs(cv.geo_aware_cv[0][:, 0].cpu().numpy() - g[name + "_geo0"]).max()
+    print(f"\nregulariser bf16x3 {name}: vs reference {err:.2e}")
+    assert err <= 2e-5
