@@ -26,7 +26,8 @@
  *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
- *     (synchronise and name every launch of the update block on stderr).
+ *     (synchronise and name every launch of the update block on stderr), NND_NO_THIN3D (the regulariser's 8- / 16-channel
+ *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip).
  */
 #ifndef NNDEPTH_AMD_H
 #define NNDEPTH_AMD_H

@@ -109,6 +109,13 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
 void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, const float* const* b, const int* cout, float* blob,
                      const int* ci_map, int cin_src);
 
+// thin3d.hip: direct fp32 VALU Conv3d for the regulariser's 8- / 16-output-channel layers (depth-major volumes)
+bool thin3d_supported(int Cout, int stride);
+int64_t thin3d_packed_floats(int Cout, int Ct);
+void thin3d_pack(int Cout, int Ct, const float* w, const float* scale, const float* shift, float* out);
+int thin3d_forward(int Cout, int C0, int C1, int stride, const float* packed, const float* x0, const float* x1, float* y, int N, int D,
+                   int H, int W, float slope, hipStream_t s);
+
 // corr1d.hip
 // `tiled`: coords / sampled features (resp. flow / mask) are tile-major workspace tensors (layout.h), else NCHW
 int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,

@@ -10,6 +10,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -195,7 +196,13 @@ int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
     if (conv3d_layer(desc, 1, &L, &t1) != NND_OK) return NND_ERR_INVALID;
     const int J = group_of(desc);
     if (J > 1 && conv3d_layer(desc, J, &L, &tj) != NND_OK) return NND_ERR_INVALID;
-    return t1 + tj;  // [plain layer | J-slice grouped layer]
+    const int64_t tt = thin3d_supported(desc->Cout, desc->stride) ? thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
+    return t1 + tj + tt;  // [plain layer | J-slice grouped layer | thin-layer VALU kernel]
+}
+
+// the thin (Cout 8 / 16) layers run on thin3d.hip unless NND_NO_THIN3D is set (diagnostic: the MFMA formulations above)
+static bool use_thin(const nnd_conv3d_desc* d) {
+    return getenv("NND_NO_THIN3D") == nullptr && thin3d_supported(d->Cout, d->stride);  // read per call: the tests toggle it
 }
 
 // 2-D weights of the J-slice grouped layer: (J*Cout, (J+2)*Ct, 3, 3) with [window of input 0: slice-major, ci][window of input 1]
@@ -246,9 +253,24 @@ int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bi
     NND_REQUIRE(!bn_gamma || (bn_beta && bn_mean && bn_var), "conv3d_pack: incomplete batch-norm parameters");
     pack_one(desc, L1, 1, w, bias, bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, packed_host);
     const int J = group_of(desc);
+    int64_t tj = 0;
     if (J > 1) {
-        if ((rc = conv3d_layer(desc, J, &LJ, nullptr)) != NND_OK) return rc;
+        if ((rc = conv3d_layer(desc, J, &LJ, &tj)) != NND_OK) return rc;
         pack_one(desc, LJ, J, w, bias, bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, packed_host + t1);
+    }
+    if (thin3d_supported(desc->Cout, desc->stride)) {  // same folded affine, weights in [ci][tap][co] order
+        std::vector<float> sc(desc->Cout), sh(desc->Cout);
+        for (int co = 0; co < desc->Cout; ++co) {
+            const double b = bias ? (double)bias[co] : 0.0;
+            double s1 = 1.0, s0 = b;
+            if (bn_gamma) {
+                s1 = (double)bn_gamma[co] / std::sqrt((double)bn_var[co] + (double)bn_eps);
+                s0 = (b - (double)bn_mean[co]) * s1 + (double)bn_beta[co];
+            }
+            sc[co] = (float)s1;
+            sh[co] = (float)s0;
+        }
+        thin3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, w, sc.data(), sh.data(), packed_host + t1 + tj);
     }
     return NND_OK;
 }
@@ -263,6 +285,22 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && x0 && y && (desc->Cin1 == 0 || x1), "conv3d_forward: null pointer");
     NND_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_forward: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (use_thin(desc)) {
+        const int st0 = desc->stride;
+        const int Do0 = (D + st0 - 1) / st0, Ho0 = (H + st0 - 1) / st0, Wo0 = (W + st0 - 1) / st0;
+        const int64_t hwo0 = (int64_t)Ho0 * Wo0;
+        for (int n = 0; n < N; ++n) {  // the zero end slices of the output
+            float* yn = y + (int64_t)n * (Do0 + 2) * desc->Cout * hwo0;
+            NND_HIP_CHECK(hipMemsetAsync(yn, 0, sizeof(float) * desc->Cout * hwo0, s));
+            NND_HIP_CHECK(hipMemsetAsync(yn + (int64_t)(Do0 + 1) * desc->Cout * hwo0, 0, sizeof(float) * desc->Cout * hwo0, s));
+        }
+        int64_t tj0 = 0;
+        const int J0 = group_of(desc);
+        ConvLayer LJ0;
+        if (J0 > 1 && (rc = conv3d_layer(desc, J0, &LJ0, &tj0)) != NND_OK) return rc;
+        return thin3d_forward(desc->Cout, desc->Cin0, desc->Cin1, st0, packed + t1 + tj0, x0, x1, y, N, D, H, W, leaky_slope, s);
+    }
     int J = group_of(desc);
     if (D % J != 0) J = 1;  // the grouped layer needs whole groups of slices; the plain one is always packed as well
     const float* blob = packed;
@@ -273,7 +311,6 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
     const int st = desc->stride;
     const int Do = (D + st - 1) / st, Ho = (H + st - 1) / st, Wo = (W + st - 1) / st;
     NND_REQUIRE(Do / J <= 65535, "conv3d_forward: depth %d exceeds the grid limit", Do);
-    hipStream_t s = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W, hwo = (int64_t)Ho * Wo;
     for (int n = 0; n < N; ++n) {
         float* yn = y + (int64_t)n * (Do + 2) * desc->Cout * hwo;

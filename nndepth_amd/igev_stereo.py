@@ -171,9 +171,8 @@ class IGEVStereoBase(nn.Module):
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, context_dim=context_dim, flow_channel=1,
                                              cor_planes=corr_levels * (2 * corr_radius + 1) * cv_groups * 2, spatial_scale=4,
                                              arithmetic=arithmetic)
-        self.cv_regularizer = self._init_cost_volume_filter()
-        if hasattr(self.cv_regularizer, "arithmetic"):
-            self.cv_regularizer.arithmetic = arithmetic
+        self.cv_regularizer = self._init_cost_volume_filter()  # its own `.arithmetic` stays "fp32": the thin Conv3d layers
+                                                               # gain nothing from the split kernel (profiles/r02_igev_regulariser_*)
         self.corr_fn = GeometryAwareCostVolume
         self.cv_squeezer = nn.Conv3d(cv_groups, 1, 3, 1, 1)
         self.tracing, self.include_preprocessing = tracing, include_preprocessing

@@ -937,10 +937,16 @@ def test_cre_transformer_maps_path_matches_token_path(cre_sd):
 # ------------------------------------------------------------ Conv3d on depth-major volumes (IGEV regulariser, a15)
 @pytest.mark.parametrize("Cout,Cin,split,stride,N,D,H,W", [
     (8, 8, 0, 1, 1, 12, 9, 14), (8, 16, 0, 1, 2, 7, 10, 12), (16, 8, 0, 2, 1, 12, 10, 16), (32, 16, 0, 2, 1, 7, 9, 11),
-    (16, 32, 16, 1, 1, 6, 8, 10), (32, 64, 32, 1, 1, 5, 6, 9), (64, 64, 0, 1, 1, 4, 5, 8)])
-def test_conv3d_norm_vs_torch(ops, Cout, Cin, split, stride, N, D, H, W):
+    (16, 32, 16, 1, 1, 6, 8, 10), (32, 64, 32, 1, 1, 5, 6, 9), (64, 64, 0, 1, 1, 4, 5, 8),
+    (8, 8, 0, 1, 1, 5, 7, 13), (16, 16, 0, 2, 1, 9, 11, 13), (8, 16, 0, 1, 1, 20, 17, 36)])
+@pytest.mark.parametrize("thin", [True, False])
+def test_conv3d_norm_vs_torch(ops, monkeypatch, thin, Cout, Cin, split, stride, N, D, H, W):
     """ConvBn3D of the IGEV regulariser (Conv3d k3 p1, stride 1/2, BatchNorm3d eval, LeakyReLU 0.01), also on a channel
     concat of two volumes, against the same PyTorch CPU ops; layout round trip included."""
+    if not thin:  # the 8- / 16-channel layers through the MFMA formulation (J-slice grouping) instead of csrc/thin3d.hip
+        if Cout > 16:
+            pytest.skip("only the thin layers have two implementations")
+        monkeypatch.setenv("NND_NO_THIN3D", "1")
     torch.manual_seed(Cout * 100 + Cin + stride)
     w = torch.randn(Cout, Cin, 3, 3, 3) * (2.0 / (Cin * 27)) ** 0.5
     bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5)
