@@ -6,8 +6,10 @@
 // epilogue / staging overhead of the generic kernel for very little K: conv1_up + final_conv ran at 26 / 19 TFLOP/s and took
 // 3.4 ms of the regulariser's 8.3 ms per 544x960 sample (profiles/r02_igev_regulariser_layers_before.txt).  Here:
 //   thread  = 4 consecutive x outputs x 1 y x 1 depth slice x all COUT channels (4*COUT accumulators, an exact fmaf chain),
-//   weights = wave-uniform: [ci][kd][kh][kw][co] in global memory, read through the scalar cache as SGPR operands of v_fma
-//             (the whole layer is <= 27.6 KB),
+//   weights = [ci][kd][kh][kw][co]: the chunk's 4 x 27 x COUT values are staged in LDS next to the slab and read back as
+//             broadcast ds_read_b128 (SGPR operands through the scalar cache were measured first: scalar loads return out of
+//             order, so every wait on them is lgkmcnt(0) and drains the LDS reads of the inputs too — 13 full drains per
+//             channel, 55 TFLOP/s; with both operands in LDS the waits are counted),
 //   input   = a (TZ+2) x 4-channel x (TY+2) x (TX+2) slab per channel chunk in LDS (32 KB, 4 workgroups per CU); a thread reads
 //             its 6 consecutive x values per (channel, kd, kh) as ds_read_b128 + ds_read_b64 and reuses them for 3 kw x 4 outputs,
 // 8 FMAs per LDS word, no structural zeros.  Two sources = the virtual channel concat of proj_2 / proj_3.
@@ -35,7 +37,8 @@ __global__ void __launch_bounds__(256) thin_conv3d_kernel(Thin3dArgs a) {
     constexpr int SX = (T3_TX - 1) * STR + 3, SY = (T3_TY - 1) * STR + 3, SZ = (T3_TZ - 1) * STR + 3;
     constexpr int RS = (SX + 3) / 4 * 4 + 4;  // slab row stride in floats: 16-B aligned rows, +4 so that rows shift banks
     constexpr int PLANE = SY * RS, CHS = SZ * PLANE, T3_CC = t3_cc(STR);
-    extern __shared__ __attribute__((aligned(16))) float slab[];  // [T3_CC][SZ][SY][RS]
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // [T3_CC][SZ][SY][RS] inputs | [T3_CC][27][COUT] weights
+    float* wl = slab + T3_CC * CHS;
     const int tid = threadIdx.x;
     const int tx = tid & 3, ty = (tid >> 2) & 7, tz = tid >> 5;
     const int tiles_x = (a.Wo + T3_TX - 1) / T3_TX;
@@ -53,50 +56,85 @@ __global__ void __launch_bounds__(256) thin_conv3d_kernel(Thin3dArgs a) {
     const int Ct = a.C0 + a.C1;
     for (int cbase = 0; cbase < Ct; cbase += T3_CC) {
         __syncthreads();  // the previous chunk's reads are done
-        // ---- stage T3_CC channels of the slab (zero outside the volume; the depth padding is in the tensor itself)
-        for (int e = tid; e < T3_CC * SZ * SY * SX; e += 256) {
-            const int sx = e % SX, r1 = e / SX;
-            const int sy = r1 % SY, r2 = r1 / SY;
-            const int sz = r2 % SZ, cc = r2 / SZ;
-            const int gx = ix0 + sx, gy = iy0 + sy, gz = iz0 + sz;  // gz: padded slice index 0..D+1
-            const int ci = cbase + cc;
-            float v = 0.f;
-            if (ci < Ct && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz <= a.D + 1) {
-                const float* src = ci < a.C0 ? a.x0 + (((long)n * (a.D + 2) + gz) * a.C0 + ci) * HW
-                                             : a.x1 + (((long)n * (a.D + 2) + gz) * a.C1 + (ci - a.C0)) * HW;
-                v = src[(long)gy * a.W + gx];
+        // ---- stage T3_CC channels of the slab (zero outside the volume; the depth padding is in the tensor itself);
+        // consecutive threads take consecutive x of a slab row; loads in batches of 8 before their LDS stores
+        constexpr int NEL = T3_CC * SZ * SY * SX, NB = 4;
+        for (int e0 = tid; e0 < NEL; e0 += 256 * NB) {
+            float v[NB];
+            int lo[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int e = e0 + 256 * k;
+                const int sx = e % SX, r1 = e / SX;
+                const int sy = r1 % SY, r2 = r1 / SY;
+                const int sz = r2 % SZ, cc = r2 / SZ;
+                const int gx = ix0 + sx, gy = iy0 + sy, gz = iz0 + sz;  // gz: padded slice index 0..D+1
+                const int ci = cbase + cc;
+                const bool ok = e < NEL && ci < Ct && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && gz <= a.D + 1;
+                const float* src = a.x0;
+                long off = 0;
+                if (ok) {
+                    if (ci < a.C0) {
+                        off = (((long)n * (a.D + 2) + gz) * a.C0 + ci) * HW + (long)gy * a.W + gx;
+                    } else {
+                        src = a.x1;
+                        off = (((long)n * (a.D + 2) + gz) * a.C1 + (ci - a.C0)) * HW + (long)gy * a.W + gx;
+                    }
+                }
+                const float t = src[off];  // unconditional (element 0 when masked): the loads of a batch are all in flight
+                v[k] = ok ? t : 0.f;
+                lo[k] = e < NEL ? cc * CHS + sz * PLANE + sy * RS + sx : -1;
             }
-            slab[cc * CHS + sz * PLANE + sy * RS + sx] = v;
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (lo[k] >= 0) slab[lo[k]] = v[k];
+        }
+        for (int e = tid; e < T3_CC * 27 * COUT; e += 256) {
+            const int ci = cbase + e / (27 * COUT);
+            wl[e] = ci < Ct ? a.w[(long)cbase * 27 * COUT + e] : 0.f;
         }
         __syncthreads();
 #pragma unroll 1
         for (int cc = 0; cc < T3_CC; ++cc) {
-            const int ci = cbase + cc;
-            if (ci >= Ct) break;
-            const float* wc = a.w + (long)ci * 27 * COUT;  // wave-uniform: scalar loads
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd)
+            if (cbase + cc >= Ct) break;
+            constexpr int NV = 3 * STR + 3;            // input x values feeding 4 outputs: 6 (stride 1) or 9 (stride 2)
+            constexpr int NVP = (NV + 3) / 4 * 4;
+            const float* wc = wl + cc * 27 * COUT;
+            auto depth_tap = [&](int kd) {
+                float xv[3][NVP];  // the 3 input rows of this depth tap
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const float* row = slab + cc * CHS + (tz * STR + kd) * PLANE + (ty * STR + kh) * RS + tx * 4 * STR;
-                    constexpr int NV = 3 * STR + 3;  // input x values feeding 4 outputs: 6 (stride 1) or 9 (stride 2)
-                    float xv[NV + (4 - NV % 4) % 4];
 #pragma unroll
-                    for (int q = 0; q < (NV + 3) / 4; ++q) {
+                    for (int q = 0; q < NVP / 4; ++q) {
                         const float4 t = *reinterpret_cast<const float4*>(row + 4 * q);
-                        xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w;
-                    }
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const float* wt = wc + ((kd * 3 + kh) * 3 + kw) * COUT;
-#pragma unroll
-                        for (int c = 0; c < COUT; ++c) {
-                            const float wv = wt[c];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i][c] = fmaf(wv, xv[i * STR + kw], acc[i][c]);
-                        }
+                        xv[kh][4 * q] = t.x; xv[kh][4 * q + 1] = t.y; xv[kh][4 * q + 2] = t.z; xv[kh][4 * q + 3] = t.w;
                     }
                 }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        float wv[COUT];
+                        const float4* wt = reinterpret_cast<const float4*>(wc + ((kd * 3 + kh) * 3 + kw) * COUT);
+#pragma unroll
+                        for (int q = 0; q < COUT / 4; ++q) {
+                            const float4 t = wt[q];  // same address in every lane: LDS broadcast
+                            wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+                        }
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i][c] = fmaf(wv[c], xv[kh][i * STR + kw], acc[i][c]);
+                    }
+            };
+            if constexpr (STR == 1 || COUT <= 8) {
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) depth_tap(kd);
+            } else {  // 16 channels at stride 2: unrolled, the hoisted LDS reads of three depth taps need 256 VGPRs (1 wave / SIMD)
+#pragma unroll 1
+                for (int kd = 0; kd < 3; ++kd) depth_tap(kd);
+            }
         }
     }
     // ---- epilogue: folded BatchNorm affine + LeakyReLU, 4 consecutive x per store
@@ -127,7 +165,7 @@ template <int COUT, int STR>
 static int launch_thin(const Thin3dArgs& a, int N, hipStream_t s) {
     constexpr int SX = (T3_TX - 1) * STR + 3, SY = (T3_TY - 1) * STR + 3, SZ = (T3_TZ - 1) * STR + 3;
     constexpr int RS = (SX + 3) / 4 * 4 + 4;
-    constexpr size_t lds = (size_t)t3_cc(STR) * SZ * SY * RS * sizeof(float);
+    constexpr size_t lds = ((size_t)t3_cc(STR) * SZ * SY * RS + (size_t)t3_cc(STR) * 27 * COUT) * sizeof(float);
     static_assert(lds <= 160 * 1024, "thin3d slab");
     auto kern = thin_conv3d_kernel<COUT, STR>;
     if (lds > 64 * 1024) {
