@@ -27,7 +27,8 @@
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
  *     (synchronise and name every launch of the update block on stderr), NND_NO_THIN3D (the regulariser's 8- / 16-channel
- *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip).
+ *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip), NND_NO_C4 (planar instead of 4-channel-
+ *     interleaved layout of the update block's conv-only workspace tensors).
  */
 #ifndef NNDEPTH_AMD_H
 #define NNDEPTH_AMD_H

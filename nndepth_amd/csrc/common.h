@@ -89,6 +89,8 @@ struct ConvIO {
     int flags = 0;         // EPI_AFFINE flags: 1 ReLU, 2 ReLU after the residual, 4 LeakyReLU with slope `scale`
     bool src_tiled = false;  // layout.h: sources are tile-major (internal workspace) instead of NCHW
     bool dst_tiled = false;  // ... out0/out1/aux0/aux1/bmap
+    bool src_c4 = false;     // tile-major with 4 channels interleaved (layout.h); channel counts / slice starts % 4 == 0
+    bool dst_c4 = false;
 };
 
 // input channels per K-chunk for a layer shape (host packer and kernels must agree)

@@ -66,8 +66,8 @@ __device__ __forceinline__ float tanhf_(float v) {
 // All loads (bias, h, z) are issued before any store: out0 may alias aux0 (GRU blend in place), which would otherwise
 // serialise load / store.
 template <int P>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&acc)[P], const int cb, const int b, const int h2,
-                                              const int reg0, const int nreg, const int (&ys)[P], const int (&xs)[P]) {
+__device__ __forceinline__ void conv_epilogue_planar(const ConvArgs& a, const f32x16 (&acc)[P], const int cb, const int b, const int h2,
+                                                     const int reg0, const int nreg, const int (&ys)[P], const int (&xs)[P]) {
     const int H = a.H, W = a.W;
     const long DP = a.ld.plane;
     const int epi = a.epi;
@@ -151,6 +151,122 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
             }
         }
     }
+}
+
+// The same for destination-side tensors in the 4-channel-interleaved tile-major layout (layout.h): registers 4q..4q+3 of a
+// lane are 4 consecutive channels of its pixel = one 16-B access per tensor (bmap / h / z loads, stores) instead of four
+// 4-B ones.  reg0 and nreg are multiples of 4 (ks = 1, 2, 4).  A last group that Cout cuts (Cout = 127 of the motion
+// encoder: its 4th channel is the flow, written by another kernel) is stored channel by channel.
+template <int P>
+__device__ __forceinline__ void conv_epilogue_c4(const ConvArgs& a, const f32x16 (&acc)[P], const int cb, const int b, const int h2,
+                                                 const int reg0, const int nreg, const int (&ys)[P], const int (&xs)[P]) {
+    const int H = a.H, W = a.W;
+    const long DP = a.ld.plane;
+    const int epi = a.epi;
+    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+    auto get = [](const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); };
+    float4 bias4[4], scale4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co0 = cb * 32 + 8 * q + 4 * h2;
+        const bool on = 4 * q >= reg0 && 4 * q < reg0 + nreg;
+        float bv[4], sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bv[i] = (!a.bmap && on && co0 + i < a.Cout) ? a.bias[co0 + i] : 0.f;
+            sv[i] = (epi == EPI_AFFINE && on && co0 + i < a.Cout) ? a.cscale[co0 + i] : 0.f;
+        }
+        bias4[q] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+        scale4[q] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+    }
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        const int y = ys[pp], x = xs[pp];
+        const bool pix_ok = (y < H && x < W);
+        const long pix = pix_ok ? pix_off(a.ld, y, x) : 0;  // already x4
+        float4 bm[4], hv[4], zv[4];
+        // ---- every load of this sub-tile first
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co0 = cb * 32 + 8 * q + 4 * h2;
+            const bool ok = pix_ok && 4 * q >= reg0 && 4 * q < reg0 + nreg && co0 + 3 < a.Cout;  // whole groups only
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            bm[q] = bias4[q];
+            hv[q] = zero;
+            zv[q] = zero;
+            if (a.bmap && ok) bm[q] = ld4(a.bmap + b * a.bmbs + (long)co0 * DP + pix);
+            if (epi == EPI_AFFINE) {
+                if (a.aux0 && ok) hv[q] = ld4(a.aux0 + b * a.abs0 + (long)co0 * DP + pix);
+            } else if (epi == EPI_GRU_Q) {
+                if (ok) {
+                    hv[q] = ld4(a.aux0 + b * a.abs0 + (long)co0 * DP + pix);
+                    zv[q] = ld4(a.aux1 + b * a.abs1 + (long)co0 * DP + pix);
+                }
+            } else if (epi == EPI_GRU_ZR) {
+                if (ok && co0 >= a.hidden) hv[q] = ld4(a.aux0 + b * a.abs0 + (long)(co0 - a.hidden) * DP + pix);
+            }
+        }
+        if (!pix_ok) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (4 * q < reg0 || 4 * q >= reg0 + nreg) continue;
+            const int co0 = cb * 32 + 8 * q + 4 * h2;
+            if (co0 >= a.Cout) continue;
+            const bool full = co0 + 3 < a.Cout;
+            float r0[4], r1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ac = acc[pp][4 * q + i];
+                const float v = ac + get(bm[q], i);
+                float o0 = v, o1 = 0.f;
+                if (epi == EPI_RELU) o0 = fmaxf(v, 0.f);
+                else if (epi == EPI_SCALE) o0 = a.scale * v;
+                else if (epi == EPI_SIGMOID_RANGE) o0 = a.scale * (sigmoidf_(v) - 0.5f) * 2.0f;
+                else if (epi == EPI_AFFINE) {
+                    float y2 = fmaf(ac, get(scale4[q], i), get(bm[q], i));
+                    if (a.flags & 4) y2 = y2 > 0.f ? y2 : a.scale * y2;
+                    if (a.flags & 1) y2 = fmaxf(y2, 0.f);
+                    if (a.aux0) y2 = get(hv[q], i) + y2;
+                    if (a.flags & 2) y2 = fmaxf(y2, 0.f);
+                    o0 = y2;
+                } else if (epi == EPI_GRU_ZR) {
+                    const float sg = sigmoidf_(v);
+                    o0 = sg;
+                    o1 = sg * get(hv[q], i);
+                } else if (epi == EPI_GRU_Q) {
+                    const float qq = tanhf_(v);
+                    o0 = (1.0f - get(zv[q], i)) * get(hv[q], i) + get(zv[q], i) * qq;
+                    o1 = o0;
+                }
+                r0[i] = o0;
+                r1[i] = o1;
+            }
+            // EPI_GRU_ZR: channel groups below `hidden` are z (out0), the others r*h (out1, channel - hidden)
+            const bool to1 = epi == EPI_GRU_ZR && co0 >= a.hidden;
+            float* d0 = to1 ? a.out1 + b * a.obs1 + (long)(co0 - a.hidden) * DP + pix : a.out0 + b * a.obs0 + (long)co0 * DP + pix;
+            const float* rr = to1 ? r1 : r0;
+            if (full) {
+                *reinterpret_cast<float4*>(d0) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                if (epi == EPI_GRU_Q && a.out1) *reinterpret_cast<float4*>(a.out1 + b * a.obs1 + (long)co0 * DP + pix) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co0 + i < a.Cout) {
+                        d0[i] = rr[i];
+                        if (epi == EPI_GRU_Q && a.out1) a.out1[b * a.obs1 + (long)co0 * DP + pix + i] = r1[i];
+                    }
+            }
+        }
+    }
+}
+
+// Epilogue of one wave: acc[pp] = the 32 (channel) x 32 (pixel) tile of sub-tile pp, this lane's pixel of it at (ys[pp], xs[pp]);
+// the wave stores registers [reg0, reg0 + nreg) (its share after an intra-workgroup split-K exchange; 0, 16 otherwise).
+template <int P>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&acc)[P], const int cb, const int b, const int h2,
+                                              const int reg0, const int nreg, const int (&ys)[P], const int (&xs)[P]) {
+    if (a.ld.ci == 4) conv_epilogue_c4<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
+    else conv_epilogue_planar<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
 }
 
 }  // namespace nnd

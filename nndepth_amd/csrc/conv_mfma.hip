@@ -135,15 +135,28 @@ conv_mfma_kernel(ConvArgs a) {
     };
     // raw loads only (clamped to element 0 when masked, so they are unconditional and hipcc counts vmcnt
     // exactly); the zero-fill select is applied in store_x, after the chunk's MFMAs
+    // channel of staging slot j: strided over the thread groups for planar sources; NE consecutive channels per thread for
+    // 4-channel-interleaved sources (layout.h), which are then NE/4 16-B loads
+    const bool c4s = a.ls.ci == 4;
+    auto slot_ch = [&](int j) { return c4s ? cg * NE + j : cg + j * ngroups; };
     auto load_x = [&](int K) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
         if (!inimg) climit = 0;
+        if (c4s) {
 #pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            const int ci = cg + j * ngroups;
-            stage[j] = src[ci < climit ? (unsigned)(ci * (int)SP + goff0) : 0u];
+            for (int q = 0; q < NE / 4; ++q) {
+                const int ci = cg * NE + 4 * q;  // multiple of 4: channel group ci/4 starts at ci*SP, like a planar channel
+                const float4 t = *reinterpret_cast<const float4*>(src + (ci < climit ? (unsigned)(ci * (int)SP + goff0) : 0u));
+                stage[4 * q] = t.x; stage[4 * q + 1] = t.y; stage[4 * q + 2] = t.z; stage[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int ci = cg + j * ngroups;
+                stage[j] = src[ci < climit ? (unsigned)(ci * (int)SP + goff0) : 0u];
+            }
         }
     };
     auto store_x = [&](int K) {
@@ -154,7 +167,7 @@ conv_mfma_kernel(ConvArgs a) {
         const int boff = (K & 1) * (SCH * PATCH);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            const int ci = cg + j * ngroups;
+            const int ci = slot_ch(j);
             const bool own = stager && ci < SCH;
             lds[own ? boff + ci * PATCH + loff0 : trash] = ci < climit ? stage[j] : 0.f;
         }
@@ -518,8 +531,12 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
-    a.ls = make_lay(Hin, Win, io.src_tiled);
-    a.ld = make_lay(H, W, io.dst_tiled);
+    a.ls = make_lay(Hin, Win, io.src_tiled, io.src_c4);
+    a.ld = make_lay(H, W, io.dst_tiled, io.dst_c4);
+    NND_REQUIRE(!io.src_c4 || (io.src_tiled && L.stride == 1 && io.src0.C % 4 == 0 && io.src1.C % 4 == 0),
+                "conv: c4 sources need stride 1 and channel counts %% 4 == 0");
+    NND_REQUIRE(!io.dst_c4 || (io.dst_tiled && (L.Cout % 4 == 0 || (!io.bmap.ptr && !io.aux0.ptr && !io.aux1.ptr && !io.out1.ptr))),
+                "conv: c4 destination with per-pixel operands needs Cout %% 4 == 0");
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
     a.Hin = Hin; a.Win = Win; a.flags = io.flags;
     a.cscale = L.s_off >= 0 ? blob + L.s_off : nullptr;
@@ -528,7 +545,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;
     a.scale = io.scale;
     static const bool no_stream = getenv("NND_NO_CONV1X1_STREAM") != nullptr;
-    if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && !io.bmap.ptr &&
+    if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && !io.src_c4 && !io.dst_c4 && !io.bmap.ptr &&
         (L.Cin == 64 || L.Cin == 96 || L.Cin == 128) &&
         (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_SCALE || epi == EPI_AFFINE)) {
         const int ntiles = cfg.tiles_x * cfg.tiles_y, KQ = L.nchunks * L.CI_T / 8;

@@ -179,14 +179,24 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
         }
     };
     // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_unit.
+    const bool c4s = a.ls.ci == 4;  // 4-channel-interleaved source: a unit's 8 channels are two 16-B loads
     auto load_unit = [&](int K, int i) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
+        if (c4s) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ci = cho[i] + j;
-            stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
+            for (int g = 0; g < 2; ++g) {
+                const int ci = cho[i] + 4 * g;  // multiple of 4: channel group ci/4 starts at ci*SP, like a planar channel
+                const float4 t = *reinterpret_cast<const float4*>(src + ((inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u));
+                stage[i][4 * g] = t.x; stage[i][4 * g + 1] = t.y; stage[i][4 * g + 2] = t.z; stage[i][4 * g + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = cho[i] + j;
+                stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
+            }
         }
     };
     auto store_unit = [&](int K, int i) {
@@ -472,8 +482,11 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
-    a.ls = make_lay(H, W, io.src_tiled);
-    a.ld = make_lay(H, W, io.dst_tiled);
+    a.ls = make_lay(H, W, io.src_tiled, io.src_c4);
+    a.ld = make_lay(H, W, io.dst_tiled, io.dst_c4);
+    NND_REQUIRE(!io.src_c4 || (io.src_tiled && io.src0.C % 4 == 0 && io.src1.C % 4 == 0), "conv_split: c4 sources need channel counts %% 4 == 0");
+    NND_REQUIRE(!io.dst_c4 || (io.dst_tiled && (L.Cout % 4 == 0 || (!io.bmap.ptr && !io.aux0.ptr && !io.aux1.ptr && !io.out1.ptr))),
+                "conv_split: c4 destination with per-pixel operands needs Cout %% 4 == 0");
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
     a.Hin = H; a.Win = W; a.flags = io.flags;
     a.cscale = L.s_off >= 0 ? blob + L.s_off : nullptr;

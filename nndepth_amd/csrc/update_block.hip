@@ -181,8 +181,10 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
 
 // coords = x (+ disp_init); flow = coords - x
 // absolute != 0 (IGEV, Q5): the update block and the upsample receive the coordinate itself, not coords - x
+// hx_flow points at the flow channel of the GRU input buffer, whose pixels are hx_pm floats apart (4 in the 4-channel-
+// interleaved layout of that buffer, 1 otherwise); coords / flow themselves are planar tile-major (`lay`)
 __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict__ flow, float* __restrict__ hx_flow,
-                                   long hx_bs, const float* __restrict__ disp_init, int B, int H, int W, int absolute, Lay lay) {
+                                   long hx_bs, int hx_pm, const float* __restrict__ disp_init, int B, int H, int W, int absolute, Lay lay) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * HW) return;
@@ -194,25 +196,27 @@ __global__ void init_coords_kernel(float* __restrict__ coords, float* __restrict
     float f = absolute ? c : c - (float)x;
     coords[b * lay.plane + po] = c;
     flow[b * lay.plane + po] = f;
-    hx_flow[b * hx_bs + po] = f;
+    hx_flow[b * hx_bs + po * hx_pm] = f;
 }
 
 // NCHW (C-ABI) <-> tile-major (workspace) copies of a C-channel tensor; dst/src batch strides in floats
-__global__ void to_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, long dbs, int B, int C, int H, int W, Lay lay) {
+// `c0`: first channel of the slice inside the workspace tensor that `dst` / `src` points at (its channel 0); src == nullptr
+// writes zeros
+__global__ void to_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, long dbs, int c0, int B, int C, int H, int W, Lay lay) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * C * HW) return;
     const long pix = idx % HW;
     const int c = (int)((idx / HW) % C), b = (int)(idx / (HW * C));
-    dst[b * dbs + c * lay.plane + pix_off(lay, (int)(pix / W), (int)(pix % W))] = src[idx];
+    dst[b * dbs + chan_off(lay, c0 + c) + pix_off(lay, (int)(pix / W), (int)(pix % W))] = src ? src[idx] : 0.f;
 }
-__global__ void from_tiled_kernel(const float* __restrict__ src, long sbs, float* __restrict__ dst, int B, int C, int H, int W, Lay lay) {
+__global__ void from_tiled_kernel(const float* __restrict__ src, long sbs, int c0, float* __restrict__ dst, int B, int C, int H, int W, Lay lay) {
     const long HW = (long)H * W;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * C * HW) return;
     const long pix = idx % HW;
     const int c = (int)((idx / HW) % C), b = (int)(idx / (HW * C));
-    dst[idx] = src[b * sbs + c * lay.plane + pix_off(lay, (int)(pix / W), (int)(pix % W))];
+    dst[idx] = src[b * sbs + chan_off(lay, c0 + c) + pix_off(lay, (int)(pix / W), (int)(pix % W))];
 }
 
 // flow_head.conv2: 3x3, hid -> FC (1 or 2) outputs.  One output channel wastes 31/32 of an MFMA tile, so this is a
@@ -224,8 +228,8 @@ template <int FC>
 __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict__ x, long xbs, int hid, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ delta,
                                                          float* __restrict__ coords, float* __restrict__ flow,
-                                                         float* __restrict__ hx_flow, long hx_bs, int H, int W, int tiles_x,
-                                                         int advance, int absolute, Lay lay) {
+                                                         float* __restrict__ hx_flow, long hx_bs, int hx_cs, int hx_pm, int H, int W,
+                                                         int tiles_x, int advance, int absolute, Lay lay) {
     // One 4x8 pixel tile per workgroup, 512 threads.  Staging: thread = (patch position, channel group of 8), its
     // loads are independent and issued back to back (clamped addresses, zero-filled by select).  Compute: thread =
     // (pixel, slice of hid/16 channels); the 16 partial sums per pixel meet in LDS.
@@ -284,13 +288,13 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
             if (advance == 2) {  // CREStereo: the state is the flow itself (cre_stereo/model.py:281), any FC
                 const float fl = flow[(b * FC + f) * HW + pix] + sum;
                 flow[(b * FC + f) * HW + pix] = fl;
-                hx_flow[b * hx_bs + f * HW + pix] = fl;
+                hx_flow[b * hx_bs + f * (long)hx_cs + pix * hx_pm] = fl;  // hx_cs: floats between the flow channels of the GRU input
             } else if (advance) {  // FC == 1 on this path
                 const float cnew = coords[b * HW + pix] + sum;
                 const float fl = absolute ? cnew : cnew - (float)xx;
                 coords[b * HW + pix] = cnew;
                 flow[b * HW + pix] = fl;
-                hx_flow[b * hx_bs + pix] = fl;
+                hx_flow[b * hx_bs + pix * hx_pm] = fl;
             }
         }
     }
@@ -298,6 +302,12 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------ sequencing
 static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
+
+// 4-channel-interleaved layout of the conv-only workspace tensors (layout.h); NND_NO_C4 (diagnostic) keeps them planar
+static bool ws_c4() { return getenv("NND_NO_C4") == nullptr; }
+// float offset of channel c / floats between consecutive pixels of a workspace tensor with plane size n
+static int64_t ws_chan(int c, int64_t n) { return ws_c4() ? (int64_t)(c / 4) * 4 * n + c % 4 : (int64_t)c * n; }
+static int ws_pm() { return ws_c4() ? 4 : 1; }
 
 // IO of conv `id` given the workspace; `corr` / `flow_src` are the external inputs.
 static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n /*plane*/, float* mask_dst, float* delta_dst) {
@@ -363,6 +373,18 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             break;
     }
     io.src_tiled = io.dst_tiled = true;  // workspace tensors are tile-major (layout.h)
+    // ... and cf, hx, z, rh, ctxb additionally keep 4 channels interleaved (ws_c4): every tensor that only the MFMA convs
+    // produce and consume.  c1 (written by the fused lookup kernels), f1 (convf1), fm (read by flow_head.conv2 and the fused
+    // mask / upsample kernel), corr, mask stay planar.
+    if (ws_c4()) {
+        switch (id) {
+            case C_C2: case C_F2: io.dst_c4 = true; break;                       // -> cf
+            case C_CV: io.src_c4 = io.dst_c4 = true; break;                      // cf -> hx[motion]
+            case C_FHM: io.src_c4 = true; break;                                 // hx[h] -> fm (planar)
+            case C_C1: case C_M2: break;
+            default: io.src_c4 = io.dst_c4 = true; break;                        // GRU convs and their context terms
+        }
+    }
     return io;
 }
 
@@ -421,13 +443,14 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     const size_t lds = (size_t)(hid * 64 + fc * hid * 9 + 16 * fc * 32) * sizeof(float);
     NND_REQUIRE(hid % 16 == 0 && lds <= 64 * 1024, "flow_head.conv2: hidden_dim %d not supported", hid);
     NND_REQUIRE(advance != 1 || fc == 1, "flow_head.conv2: the coordinate advance needs flow_channels == 1");
-    float* hx_flow = w.hx + (hxC - fc) * n;
+    float* hx_flow = w.hx + ws_chan(hxC - fc, n);
+    const int hx_cs = (int)(ws_chan(hxC - fc + 1, n) - ws_chan(hxC - fc, n));  // floats between the flow channels inside hx
     if (fc == 1)
         hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance, absolute ? 1 : 0, lay);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), H, W, tiles_x, advance, absolute ? 1 : 0, lay);
     else
         hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
     NND_LAUNCH_CHECK();
     return debug_sync("flow_head.conv2", s);
 }
@@ -516,15 +539,19 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
     return NND_OK;
 }
 
-static int to_tiled(const float* src, float* dst, int64_t dbs, int B, int C, int H, int W, hipStream_t s) {
+// NCHW <-> workspace tensor `dst` / `src` (its channel 0), slice of C channels starting at channel c0; c4: that tensor is in
+// the 4-channel-interleaved layout; src == nullptr (to_tiled) writes zeros
+static int to_tiled(const float* src, float* dst, int64_t dbs, int B, int C, int H, int W, hipStream_t s, int c0 = 0, bool c4 = false) {
     const long total = (long)B * C * H * W;
-    hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, src, dst, (long)dbs, B, C, H, W, make_lay(H, W, true));
+    hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, src, dst, (long)dbs, c0, B, C, H, W,
+                       make_lay(H, W, true, c4));
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
-static int from_tiled(const float* src, int64_t sbs, float* dst, int B, int C, int H, int W, hipStream_t s) {
+static int from_tiled(const float* src, int64_t sbs, float* dst, int B, int C, int H, int W, hipStream_t s, int c0 = 0, bool c4 = false) {
     const long total = (long)B * C * H * W;
-    hipLaunchKernelGGL(from_tiled_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, src, (long)sbs, dst, B, C, H, W, make_lay(H, W, true));
+    hipLaunchKernelGGL(from_tiled_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, src, (long)sbs, c0, dst, B, C, H, W,
+                       make_lay(H, W, true, c4));
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
@@ -635,14 +662,14 @@ int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* pac
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, fc = p.d.flow_channels, hxC = 2 * hid + ctx;
     const int64_t n = tiled_plane(H, W);
     // C-ABI tensors are NCHW, the workspace is tile-major: convert on the way in and out
-    NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s));
-    NND_TRY(to_tiled(inp, w.hx + hid * n, hxC * n, B, ctx, H, W, s));
-    NND_TRY(to_tiled(flow, w.hx + (hxC - fc) * n, hxC * n, B, fc, H, W, s));
+    NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s, 0, ws_c4()));
+    NND_TRY(to_tiled(inp, w.hx, hxC * n, B, ctx, H, W, s, hid, ws_c4()));
+    NND_TRY(to_tiled(flow, w.hx, hxC * n, B, fc, H, W, s, hxC - fc, ws_c4()));
     NND_TRY(to_tiled(flow, w.flow, fc * n, B, fc, H, W, s));
     NND_TRY(to_tiled(corr, w.corr, p.d.cor_planes * n, B, p.d.cor_planes, H, W, s));
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
     NND_TRY(run_update(p, packed, w, c, w.flow, mask_out ? w.mask : nullptr, w.delta, B, H, W, s));
-    NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
+    NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s, 0, ws_c4()));
     NND_TRY(from_tiled(w.delta, fc * n, delta_out, B, fc, H, W, s));
     if (mask_out) NND_TRY(from_tiled(w.mask, p.d.mask_channels * n, mask_out, B, p.d.mask_channels, H, W, s));
     return NND_OK;
@@ -705,20 +732,20 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const int hid = p.d.hidden_dim, ctx = p.d.context_dim, hxC = 2 * hid + ctx;
     const Lay lay = make_lay(H, W, true);
     const int64_t n = lay.plane;  // channel stride of every (tile-major) workspace tensor
-    NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s));
-    NND_TRY(to_tiled(inp, w.hx + hid * n, hxC * n, B, ctx, H, W, s));
-    float* hx_flow = w.hx + (hxC - fc) * n;
+    NND_TRY(to_tiled(net, w.hx, hxC * n, B, hid, H, W, s, 0, ws_c4()));
+    NND_TRY(to_tiled(inp, w.hx, hxC * n, B, ctx, H, W, s, hid, ws_c4()));
+    float* hx_flow = w.hx + ws_chan(hxC - fc, n);
     const unsigned eg = (unsigned)cdiv64((int64_t)B * H * W, 256);
     if (cre) {
         if (disp_init) {
             NND_TRY(to_tiled(disp_init, w.flow, fc * n, B, fc, H, W, s));
-            NND_TRY(to_tiled(disp_init, hx_flow, hxC * n, B, fc, H, W, s));
+            NND_TRY(to_tiled(disp_init, w.hx, hxC * n, B, fc, H, W, s, hxC - fc, ws_c4()));
         } else {
             NND_HIP_CHECK(hipMemsetAsync(w.flow, 0, sizeof(float) * B * fc * n, s));
-            for (int b = 0; b < B; ++b) NND_HIP_CHECK(hipMemsetAsync(hx_flow + b * hxC * n, 0, sizeof(float) * fc * n, s));
+            NND_TRY(to_tiled(nullptr, w.hx, hxC * n, B, fc, H, W, s, hxC - fc, ws_c4()));  // zero flow channels of the GRU input
         }
     } else {
-        hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), disp_init, B, H,
+        hipLaunchKernelGGL(init_coords_kernel, dim3(eg), dim3(256), 0, s, w.coords, w.flow, hx_flow, (long)(hxC * n), ws_pm(), disp_init, B, H,
                            W, igev ? 1 : 0, lay);
         NND_LAUNCH_CHECK();
     }
@@ -797,7 +824,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     }
     // (the side stream is joined back into `s` by ~ForkJoin; its last result was consumed already)
     if (low_out) NND_TRY(from_tiled(w.flow, fc * n, low_out, B, fc, H, W, s));
-    if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s));
+    if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s, 0, ws_c4()));
     return NND_OK;
 }
 

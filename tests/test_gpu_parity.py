@@ -366,6 +366,34 @@ def test_refine_wrappers_validate_shapes(raft_sd):
         eng.refine(pyr, 4, 4, net, inp, 8, 1, disp_init=torch.zeros(B, 1, H, W + 1, device=DEV))
 
 
+@pytest.mark.parametrize("arithmetic", ["fp32", "bf16x3"])
+def test_c4_workspace_layout_is_bit_identical_to_planar(raft_sd, monkeypatch, arithmetic):
+    """The conv-only workspace tensors (cf, hx, z, rh, ctxb) keep 4 channels interleaved (csrc/layout.h): a pure change of
+    addresses — 16-B staging loads and epilogue accesses instead of 4-B ones — so every output must equal the planar
+    tile-major run (NND_NO_C4) bit for bit: fused loop (ragged 12x20 tiles, batch 2) and the single-call update block."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+
+    def run():
+        m = BaseRAFTStereo(iters=5, context_dim=64, arithmetic=arithmetic)
+        m.load_state_dict(raft_sd, strict=True)
+        m = m.to(DEV).eval()
+        f1, f2 = weightgen.synthetic_frames(9, 2, 96, 160)
+        outs = [o["up_disp"].clone() for o in m(f1.to(DEV), f2.to(DEV))]
+        torch.manual_seed(3)
+        net, inp = torch.tanh(torch.randn(2, 128, 12, 20)), torch.relu(torch.randn(2, 64, 12, 20))
+        corr, flow = torch.randn(2, 36, 12, 20), torch.randn(2, 1, 12, 20) * 4
+        outs += [t_.clone() for t_ in m.update_block(net.to(DEV), inp.to(DEV), corr.to(DEV), flow.to(DEV))]
+        return outs
+
+    a = run()
+    monkeypatch.setenv("NND_NO_C4", "1")
+    b = run()
+    assert len(a) == len(b) == 8
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
 def test_fused_mask_upsample_matches_unfused(raft_sd, monkeypatch):
     """The fused mask.2+softmax+upsample kernel (mask never written) == mask.2 conv followed by the
     standalone convex_upsample kernel, on the same loop (seam-by-seam path uses the unfused kernels)."""
