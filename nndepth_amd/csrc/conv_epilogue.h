@@ -42,7 +42,7 @@ __device__ __forceinline__ float exp_acc(float x) {
     const float L2E = 1.44269504088896341f;
     x = fminf(fmaxf(x, -87.0f), 88.0f);
     const float t = x * L2E;
-    const float r = fmaf(x, L2E, -t) + x * 1.92596299e-8f;  // + x * (log2e - (float)log2e)
+    const float r = fmaf(x, 1.92596299e-8f, fmaf(x, L2E, -t));  // + x * (log2e - (float)log2e); explicit fma: no context-dependent contraction
     const float e = __builtin_amdgcn_exp2f(t);
     return fmaf(e, r * 0.693147180559945f, e);
 }
@@ -55,7 +55,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return rcp_acc(1.0f + exp_
 // tanh(x) = sign(x) * (1 - 2/(exp(2|x|) + 1)); for |x| < 0.04 the odd series avoids the cancellation
 __device__ __forceinline__ float tanhf_(float v) {
     const float ax = fabsf(v);
-    const float big = 1.0f - 2.0f * rcp_acc(exp_acc(2.0f * ax) + 1.0f);
+    const float big = fmaf(-2.0f, rcp_acc(exp_acc(2.0f * ax) + 1.0f), 1.0f);
     const float x2 = ax * ax;
     const float small = ax * fmaf(x2, fmaf(x2, 0.133333333f, -0.333333333f), 1.0f);
     return copysignf(ax < 0.04f ? small : big, v);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void conv_epilogue_planar(const ConvArgs& a, const f3
                 else a.out1[b * a.obs1 + (co - a.hidden) * DP + pix] = sg * h_r[reg];
             } else {  // EPI_GRU_Q
                 const float q = tanhf_(v);
-                const float hn = (1.0f - z_r[reg]) * h_r[reg] + z_r[reg] * q;
+                const float hn = fmaf(z_r[reg], q, (1.0f - z_r[reg]) * h_r[reg]);  // explicit: both layouts' epilogues round alike
                 a.out0[b * a.obs0 + co * DP + pix] = hn;
                 if (a.out1) a.out1[b * a.obs1 + co * DP + pix] = hn;
             }
@@ -235,7 +235,7 @@ __device__ __forceinline__ void conv_epilogue_c4(const ConvArgs& a, const f32x16
                     o1 = sg * get(hv[q], i);
                 } else if (epi == EPI_GRU_Q) {
                     const float qq = tanhf_(v);
-                    o0 = (1.0f - get(zv[q], i)) * get(hv[q], i) + get(zv[q], i) * qq;
+                    o0 = fmaf(get(zv[q], i), qq, (1.0f - get(zv[q], i)) * get(hv[q], i));
                     o1 = o0;
                 }
                 r0[i] = o0;
