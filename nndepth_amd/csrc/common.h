@@ -135,10 +135,10 @@ int agcl_offset_launch(const float* f1, const float* f2, const float* flow, cons
                        int W, int small_patch, hipStream_t s, bool tiled);
 int agcl_check(const char* what, int N, int C, int H, int W);
 int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
-                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream);
+                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
 bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius);
 int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, const ConvLayer& L, const float* blob, float* c1,
-                                 int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream);
+                                 int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
 bool mask_upsample_supported(int rate, int cin, int flow_channels);
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
                          int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1);

@@ -425,6 +425,29 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
     return NND_OK;
 }
 
+// relu(acc + bias) of one lane's pixel and 16 channels into c1: planar tile-major, or (out_c4) the 4-channel-interleaved
+// tile-major layout of layout.h, where registers 4q..4q+3 are one 16-B store
+__device__ __forceinline__ void store_c1(float* __restrict__ out_b, const Lay& lay, int y, int x, int cb, int h2, const f32x16& acc,
+                                         const float* __restrict__ bias, int out_c4) {
+    const long po = pix_off(lay, y, x);  // lay: the planar tile-major layout of coords (ci = 1)
+    if (out_c4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co0 = cb * 32 + 8 * q + 4 * h2;
+            *reinterpret_cast<float4*>(out_b + (long)co0 * lay.plane + po * 4) =
+                make_float4(fmaxf(acc[4 * q] + bias[co0], 0.f), fmaxf(acc[4 * q + 1] + bias[co0 + 1], 0.f),
+                            fmaxf(acc[4 * q + 2] + bias[co0 + 2], 0.f), fmaxf(acc[4 * q + 3] + bias[co0 + 3], 0.f));
+        }
+    } else {
+        float* o = out_b + po;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+            o[(long)co * lay.plane] = fmaxf(acc[reg] + bias[co], 0.f);
+        }
+    }
+}
+
 // Fused lookup + encoder.convc1 (1x1, cor_planes -> 256, ReLU) for the refinement loops: one workgroup = one 4x8 pixel
 // tile x all 256 output channels (8 waves).  The sampled correlation features are produced 32 channels at a time
 // straight into the LDS B-operand (same arithmetic and op order as corr1d_lookup_kernel / igev_lookup_kernel; the two
@@ -436,7 +459,7 @@ template <bool IGEV>
 __global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restrict__ pyr, const float* __restrict__ geo,
                                                             const float* __restrict__ coords, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, float* __restrict__ out, long obs,
-                                                            LookupArgs a, int G, int tiles_x, int cb_stride) {
+                                                            LookupArgs a, int G, int tiles_x, int cb_stride, int out_c4) {
     __shared__ float xs[2][32 * 32];  // [buffer][channel of the chunk][pixel of the tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -511,18 +534,13 @@ __global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restr
     }
     const int y = ty0 + (l31 >> 3), x = tx0 + (l31 & 7);
     if (y >= a.H || x >= a.W) return;
-    float* o = out + (long)b * obs + pix_off(a.lay, y, x);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-        o[(long)co * a.lay.plane] = fmaxf(acc[reg] + bias[co], 0.f);
-    }
+    store_c1(out + (long)b * obs, a.lay, y, x, cb, h2, acc, bias, out_c4);
 }
 
 // coords (tile-major) -> c1 = relu(convc1(lookup(coords))) (tile-major, 256 channels); wpk / bias: the packed convc1 layer.
 // geo == nullptr: RAFT-Stereo pyramid; otherwise the IGEV feature + geometry pyramids with G groups.
 int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
-                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream) {
+                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4) {
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 &&
                     L.Cin == num_levels * (2 * radius + 1) * (geo ? 2 * G : 1),
                 "lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
@@ -538,9 +556,9 @@ int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float*
     const int tiles_x = cdiv(W, 8);
     dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(512);
     if (geo)
-        hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, G, tiles_x, cb_stride);
+        hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, G, tiles_x, cb_stride, c1_c4 ? 1 : 0);
     else
-        hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, 1, tiles_x, cb_stride);
+        hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, 1, tiles_x, cb_stride, c1_c4 ? 1 : 0);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
@@ -600,7 +618,7 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_kernel(const flo
                                                                       const float* __restrict__ wpk, const float* __restrict__ bias,
                                                                       float* __restrict__ out, long obs, ILayout IL, Lay lay,
                                                                       int H, int W, int num_levels, int ntiles, int tiles_x,
-                                                                      int cb_stride) {
+                                                                      int cb_stride, int out_c4) {
     extern __shared__ float xs[];  // [2][IL_LC][IL_S]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -688,12 +706,7 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_kernel(const flo
         const int t = blockIdx.x * 2 + p;
         const int y = (t / tiles_x) * 4 + (l31 >> 3), x = (t % tiles_x) * 8 + (l31 & 7);
         if (t >= ntiles || y >= H || x >= W) continue;
-        float* o = out + (long)b * obs + pix_off(lay, y, x);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-            o[(long)co * lay.plane] = fmaxf((p ? acc1[reg] : acc0[reg]) + bias[co], 0.f);
-        }
+        store_c1(out + (long)b * obs, lay, y, x, wave, h2, p ? acc1 : acc0, bias, out_c4);
     }
 }
 
@@ -703,7 +716,7 @@ bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius) {
 }
 
 int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, const ConvLayer& L, const float* blob, float* c1,
-                                 int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream) {
+                                 int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4) {
     NND_REQUIRE(igev_lookup_convc1_il_supported(G, num_levels, radius), "igev_lookup_convc1: groups %d / radius %d not built", G, radius);
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 && L.Cin == num_levels * IL_LC,
                 "igev_lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
@@ -720,7 +733,7 @@ int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, co
     const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
     const int cb_stride = L.nchunks * (L.CI_T / 8) * 64;
     hipLaunchKernelGGL(igev_lookup_convc1_il_kernel, dim3(cdiv(ntiles, 2), 1, B), dim3(512), lds, stream, il, coords, blob + L.w_off,
-                       blob + L.b_off, c1, (long)c1_bs, IL, make_lay(H, W, true), H, W, num_levels, ntiles, tiles_x, cb_stride);
+                       blob + L.b_off, c1, (long)c1_bs, IL, make_lay(H, W, true), H, W, num_levels, ntiles, tiles_x, cb_stride, c1_c4 ? 1 : 0);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

@@ -373,15 +373,17 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             break;
     }
     io.src_tiled = io.dst_tiled = true;  // workspace tensors are tile-major (layout.h)
-    // ... and cf, hx, z, rh, ctxb additionally keep 4 channels interleaved (ws_c4): every tensor that only the MFMA convs
-    // produce and consume.  c1 (written by the fused lookup kernels), f1 (convf1), fm (read by flow_head.conv2 and the fused
-    // mask / upsample kernel), corr, mask stay planar.
+    // ... and c1, cf, hx, z, rh, ctxb additionally keep 4 channels interleaved (ws_c4): the tensors that the MFMA convs (and
+    // the fused lookup + convc1 kernels) produce and consume.  f1 (convf1), fm (read by flow_head.conv2 and the fused mask /
+    // upsample kernel), corr, mask stay planar.
     if (ws_c4()) {
         switch (id) {
-            case C_C2: case C_F2: io.dst_c4 = true; break;                       // -> cf
+            case C_C1: io.dst_c4 = true; break;                                  // corr (planar) -> c1
+            case C_C2: io.src_c4 = io.dst_c4 = true; break;                      // c1 -> cf
+            case C_F2: io.dst_c4 = true; break;                                  // f1 (planar) -> cf
             case C_CV: io.src_c4 = io.dst_c4 = true; break;                      // cf -> hx[motion]
             case C_FHM: io.src_c4 = true; break;                                 // hx[h] -> fm (planar)
-            case C_C1: case C_M2: break;
+            case C_M2: break;
             default: io.src_c4 = io.dst_c4 = true; break;                        // GRU convs and their context terms
         }
     }
@@ -793,10 +795,10 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
         if (fused_lk && interleaved && igev_lookup_convc1_il_supported(groups, num_levels, radius)) {  // IGEV over the group-interleaved copy of both pyramids
             NND_TRY(igev_lookup_convc1_il_launch(interleaved, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W, num_levels,
-                                                 radius, s));
+                                                 radius, s, ws_c4()));
         } else if (fused_lk) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
             NND_TRY(lookup_convc1_launch(pyramid, geo_pyramid, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W,
-                                         num_levels, radius, s));
+                                         num_levels, radius, s, ws_c4()));
         } else {
             NND_TRY(lookup(s, it));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
