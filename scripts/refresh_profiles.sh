@@ -34,3 +34,8 @@ print(open("$O/pmc_conv_traffic.txt").read())
 PY
 find $O/pmc_fetch $O/pmc_write $O/pmc_sq -name "*.csv" -size +1M -delete
 tail -1 $O/bench_line.json | python scripts/bench_summary.py
+# other configurations (per-GPU work of BASELINE.json configs 3, 4, 5, both arithmetics) and the IGEV regulariser per layer
+python scripts/bench_configs.py > $O/other_configs.txt 2>&1 || true
+python scripts/prof_regulariser_layers.py > $O/igev_regulariser_layers.txt 2>&1 || true
+python scripts/prof_split.py > $O/split_vs_fp32_68x120.txt 2>&1 || true
+python scripts/prof_split.py 136 240 > $O/split_vs_fp32_136x240.txt 2>&1 || true
