@@ -141,6 +141,6 @@ int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, co
                                  int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
 bool mask_upsample_supported(int rate, int cin, int flow_channels);
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1);
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1, bool x_c4 = false);
 
 }  // namespace nnd

@@ -28,6 +28,7 @@ struct MaskUpArgs {
     float* out;         // (B,FC,R*H,R*W)
     int H, W, tiles_x, fc;  // fc: flow channels, 1 (RAFT/IGEV disparity) or 2 (CREStereo flow)
     Lay lay;  // layout of x and flow (tile-major inside the loop, NCHW through the C-ABI)
+    int x_c4;  // x keeps 4 channels interleaved (tile-major c4, layout.h); flow stays planar
 };
 
 template <int RATE, int CIN>
@@ -69,6 +70,30 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     // ---- stage the x tile (all CIN channels) and the flow patch
     {
         const float* src = a.x + b * a.xbs;
+        if (a.x_c4) {  // one 16-B load per (pixel, 4 channels)
+            constexpr int NQ4 = (CIN / 4 * 32 + NT - 1) / NT;
+            float4 v4[NQ4];
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) {
+                const int e = tid + i * NT;
+                const int qd = e >> 5, px = e & 31;
+                const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
+                const bool ok = e < CIN / 4 * 32 && y < H && x < W;
+                v4[i] = *reinterpret_cast<const float4*>(src + (ok ? (unsigned)(qd * 4 * (int)XP + 4 * (int)pix_off(a.lay, y, x)) : 0u));
+            }
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) {
+                const int e = tid + i * NT;
+                const int qd = e >> 5, px = e & 31;
+                const bool ok = (ty0 + (px >> 3)) < H && (tx0 + (px & 7)) < W;
+                if (e < CIN / 4 * 32) {
+                    xs[(qd * 4 + 0) * 32 + px] = ok ? v4[i].x : 0.f;
+                    xs[(qd * 4 + 1) * 32 + px] = ok ? v4[i].y : 0.f;
+                    xs[(qd * 4 + 2) * 32 + px] = ok ? v4[i].z : 0.f;
+                    xs[(qd * 4 + 3) * 32 + px] = ok ? v4[i].w : 0.f;
+                }
+            }
+        } else {
         constexpr int NLD = (CIN * 32 + NT - 1) / NT;
         float v[NLD];
 #pragma unroll
@@ -85,6 +110,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             const int px = e & 31;
             const bool ok = (ty0 + (px >> 3)) < H && (tx0 + (px & 7)) < W;
             if (e < CIN * 32) xs[e] = ok ? v[i] : 0.f;
+        }
         }
         if (tid < 60 * a.fc) {
             const int f = tid / 60, pos = tid % 60;
@@ -218,7 +244,7 @@ bool mask_upsample_supported(int rate, int cin, int flow_channels) {
 }
 
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels) {
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels, bool x_c4) {
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == 128 && L.Cout == 9 * rate * rate, "mask_upsample: layer shape");
     NND_REQUIRE(mask_upsample_supported(rate, L.Cin, flow_channels), "mask_upsample: rate %d / Cin %d / %d flow channels not built",
                 rate, L.Cin, flow_channels);
@@ -226,6 +252,7 @@ int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, 
     a.x = x; a.xbs = xbs; a.wpk = blob + L.w_off; a.bias = blob + L.b_off; a.flow = flow; a.out = out;
     a.H = H; a.W = W; a.tiles_x = cdiv(W, 8); a.fc = flow_channels;
     a.lay = make_lay(H, W, tiled);
+    a.x_c4 = (tiled && x_c4) ? 1 : 0;
     if (rate == 8 && L.Cin == 256) return launch_mu<8, 256>(a, B, stream);
     if (rate == 8 && L.Cin == 128) return launch_mu<8, 128>(a, B, stream);
     if (rate == 4 && L.Cin == 256) return launch_mu<4, 256>(a, B, stream);

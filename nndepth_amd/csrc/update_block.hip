@@ -147,6 +147,11 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
                                                      const float* __restrict__ bias, float* __restrict__ out, long obs,
                                                      int H, int W, int tiles_x, Lay lay) {
     __shared__ float patch[FC][14][40];
+    // the workgroup's 16 x FC*49 weights, read back as LDS broadcasts.  (Round 1 read them through the scalar cache as SGPR
+    // operands: 16 dependent s_load batches per thread, each a scalar-cache miss, made this 0.1-GFLOP kernel take 26 us on the
+    // side stream, where it slowed the concurrent convc2 from 48 to 63 us.)
+    __shared__ __attribute__((aligned(16))) float wl[16 * (FC * 49 + 3)];
+    constexpr int WS = FC * 49 + 3;  // row stride: multiple of 4 floats
     const int tid = threadIdx.x;
     const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
     const int b = blockIdx.z, co0 = blockIdx.y * 16;
@@ -157,6 +162,7 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
         int gy = ty0 + pr - 3, gx = tx0 + pc - 3;
         patch[c][pr][pc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? flow[b * fbs + c * HW + pix_off(lay, gy, gx)] : 0.f;
     }
+    for (int e = tid; e < 16 * FC * 49; e += 256) wl[(e / (FC * 49)) * WS + e % (FC * 49)] = w[(long)co0 * (FC * 49) + e];
     __syncthreads();
     const int st = tid >> 5, within = tid & 31;  // sub-tile (2 rows x 4 cols of them), pixel inside it
     const int ty = (st >> 2) * 4 + (within >> 3), tx = (st & 3) * 8 + (within & 7);
@@ -169,13 +175,14 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
             for (int dx = 0; dx < 7; ++dx) v[c * 49 + dy * 7 + dx] = patch[c][ty + dy][tx + dx];
     const int y = ty0 + ty, x = tx0 + tx;
     const bool ok = y < H && x < W;
-    for (int co = co0; co < co0 + 16; ++co) {
-        const float* wc = w + (long)co * (FC * 49);
+#pragma unroll 4
+    for (int cc = 0; cc < 16; ++cc) {
+        const float* wc = wl + cc * WS;  // same address in every lane: broadcast reads
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < FC * 49; ++i) acc = fmaf(wc[i], v[i], acc);
-        acc += bias[co];
-        if (ok) out[b * obs + co * HW + pix_off(lay, y, x)] = fmaxf(acc, 0.f);
+        acc += bias[co0 + cc];
+        if (ok) out[b * obs + (co0 + cc) * HW + pix_off(lay, y, x)] = fmaxf(acc, 0.f);
     }
 }
 
@@ -228,8 +235,8 @@ template <int FC>
 __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict__ x, long xbs, int hid, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ delta,
                                                          float* __restrict__ coords, float* __restrict__ flow,
-                                                         float* __restrict__ hx_flow, long hx_bs, int hx_cs, int hx_pm, int H, int W,
-                                                         int tiles_x, int advance, int absolute, Lay lay) {
+                                                         float* __restrict__ hx_flow, long hx_bs, int hx_cs, int hx_pm, int x_c4, int H,
+                                                         int W, int tiles_x, int advance, int absolute, Lay lay) {
     // One 4x8 pixel tile per workgroup, 512 threads.  Staging: thread = (patch position, channel group of 8), its
     // loads are independent and issued back to back (clamped addresses, zero-filled by select).  Compute: thread =
     // (pixel, slice of hid/16 channels); the 16 partial sums per pixel meet in LDS.
@@ -246,6 +253,22 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
         const int gy = ty0 + pos / 10 - 1, gx = tx0 + pos % 10 - 1;
         const bool ok = pos < 60 && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const long off = ok ? pix_off(lay, gy, gx) : 0;
+        if (x_c4) {  // x keeps 4 channels interleaved: one 16-B load per channel quad
+            for (int q0 = cg; q0 < hid / 4; q0 += 32) {  // 4 loads in flight per thread
+                float4 v4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v4[j] = *reinterpret_cast<const float4*>(src + (long)min(q0 + 8 * j, hid / 4 - 1) * 4 * HW + 4 * off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q0 + 8 * j < hid / 4) {
+                        float* pp = patch + (q0 + 8 * j) * 4 * 64 + pos;
+                        pp[0] = ok ? v4[j].x : 0.f;
+                        pp[64] = ok ? v4[j].y : 0.f;
+                        pp[128] = ok ? v4[j].z : 0.f;
+                        pp[192] = ok ? v4[j].w : 0.f;
+                    }
+            }
+        } else
         for (int c0 = cg; c0 < hid; c0 += 64) {  // 8 loads in flight per thread
             float v[8];
 #pragma unroll
@@ -373,17 +396,17 @@ static ConvIO conv_io(const Plan& p, const Bufs& w, int id, Act corr, int64_t n 
             break;
     }
     io.src_tiled = io.dst_tiled = true;  // workspace tensors are tile-major (layout.h)
-    // ... and c1, cf, hx, z, rh, ctxb additionally keep 4 channels interleaved (ws_c4): the tensors that the MFMA convs (and
-    // the fused lookup + convc1 kernels) produce and consume.  f1 (convf1), fm (read by flow_head.conv2 and the fused mask /
-    // upsample kernel), corr, mask stay planar.
+    // ... and c1, cf, hx, z, rh, fm, ctxb additionally keep 4 channels interleaved (ws_c4): the tensors that the MFMA convs,
+    // the fused lookup + convc1 kernels, flow_head.conv2 and the fused mask / upsample kernel produce and consume.
+    // f1 (convf1), corr, mask, flow, coords stay planar.
     if (ws_c4()) {
         switch (id) {
             case C_C1: io.dst_c4 = true; break;                                  // corr (planar) -> c1
             case C_C2: io.src_c4 = io.dst_c4 = true; break;                      // c1 -> cf
             case C_F2: io.dst_c4 = true; break;                                  // f1 (planar) -> cf
             case C_CV: io.src_c4 = io.dst_c4 = true; break;                      // cf -> hx[motion]
-            case C_FHM: io.src_c4 = true; break;                                 // hx[h] -> fm (planar)
-            case C_M2: break;
+            case C_FHM: io.src_c4 = io.dst_c4 = true; break;                     // hx[h] -> fm
+            case C_M2: io.src_c4 = true; break;                                  // fm -> mask (planar; unfused path only)
             default: io.src_c4 = io.dst_c4 = true; break;                        // GRU convs and their context terms
         }
     }
@@ -449,10 +472,10 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     const int hx_cs = (int)(ws_chan(hxC - fc + 1, n) - ws_chan(hxC - fc, n));  // floats between the flow channels inside hx
     if (fc == 1)
         hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), H, W, tiles_x, advance, absolute ? 1 : 0, lay);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance, absolute ? 1 : 0, lay);
     else
         hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
-                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
+                           delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
     NND_LAUNCH_CHECK();
     return debug_sync("flow_head.conv2", s);
 }
@@ -818,7 +841,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         float* up_it = up_out + (int64_t)it * up_iter_stride;
         if (fused_up) {  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
             NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow, up_it, B, H, W, rate, s,
-                                         true, fc));
+                                         true, fc, ws_c4()));
         } else {
             NND_TRY(run_conv(p, packed, w, C_M2, c, w.mask, nullptr, B, H, W, s));
             NND_TRY(convex_upsample_launch(w.flow, w.mask, up_it, B, fc, H, W, rate, s, true));
