@@ -24,7 +24,7 @@
  *     equivalent, never a non-HIP path): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
  *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
  *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
- *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_CONV_CFG / NND_CONV_P
+ *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_AGCL_V1 (one-pixel-per-lane AGCL kernels), NND_AGCL_PB (pixels per workgroup of the channels-last offset kernel), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
  *     (synchronise and name every launch of the update block on stderr), NND_NO_THIN3D (the regulariser's 8- / 16-channel
  *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip), NND_NO_C4 (planar instead of 4-channel-
@@ -118,6 +118,12 @@ int nnd_agcl_corr_iter(const float* fmap1, const float* fmap2, const float* flow
                        int N, int C, int H, int W, int small_patch, void* stream);
 int nnd_agcl_corr_offset(const float* fmap1, const float* fmap2, const float* flow, const float* extra_offset, float* out,
                          int N, int C, int H, int W, int small_patch, void* stream);
+/* The same on channels-last copies (N,H,W,C) of the two maps, C == 256 (the maps are constant over the iterations of a
+ * cascade stage, the copy is made once): one wave per pixel, every bilinear tap is one 1-KB line.  Sums the 64 channels
+ * of a group in a different order than nnd_agcl_corr_offset (<= 1e-7 apart).  nnd_nchw_to_nhwc makes the copy.        */
+int nnd_agcl_corr_offset_nhwc(const float* fmap1_nhwc, const float* fmap2_nhwc, const float* flow, const float* extra_offset,
+                              float* out, int N, int C, int H, int W, int small_patch, void* stream);
+int nnd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, void* stream);
 
 /* IGEV initial disparity: regress_disparity(softmax over the candidate axis)
  *   nndepth/models/igev_stereo/model.py:92-95,145-146
@@ -354,8 +360,9 @@ int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packe
  * flow += delta -> 2-channel convex upsample.  Iteration i searches a 1x9 window when i is even, 3x3 when odd.
  * extra_offset == NULL: iter mode (nnd_agcl_corr_iter; `warped` = caller-owned scratch of B*C*H*W floats);
  * extra_offset (B,18,H,W): offset mode (nnd_agcl_corr_offset; fmap1/fmap2 already attended by the caller; `warped`
- * may be NULL).  flow_init (B,2,H,W) or NULL for zero.  up_out: iteration i writes (B,2,rate*H,rate*W) at
- * up_out + i*up_iter_stride; low_out (optional) the final flow (B,2,H,W); net_out (optional) the hidden state.   */
+ * = scratch of 2*B*C*H*W floats for the channels-last copies of the two maps that nnd_agcl_corr_offset_nhwc samples, or
+ * NULL / C != 256: the planar kernel, same results to 1e-7, slower).  flow_init (B,2,H,W) or NULL for zero.
+ * up_out: iteration i writes (B,2,rate*H,rate*W) at up_out + i*up_iter_stride; low_out (optional) the final flow (B,2,H,W); net_out (optional) the hidden state.   */
 int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
                           const float* fmap1, const float* fmap2, int C, const float* extra_offset, float* warped,
                           const float* net, const float* inp, const float* flow_init,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "nnd_bilinear_sample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_agcl_corr_iter": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_agcl_corr_offset": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_agcl_corr_offset_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "nnd_update_block_num_tensors": (_I, [C.POINTER(UpdateBlockDesc)]),
     "nnd_update_block_packed_floats": (C.c_int64, [C.POINTER(UpdateBlockDesc)]),
     "nnd_update_block_pack": (_I, [C.POINTER(UpdateBlockDesc), C.POINTER(_P), _P]),

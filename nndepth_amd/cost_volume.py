@@ -103,6 +103,7 @@ class AGCL:
         self.att = att
         self._scratch = None  # warped right features of iter mode, reused over the iterations
         self._attended = None  # att(fmap1, fmap2): constant over the iterations of a stage (inference), computed once
+        self._nhwc = None  # channels-last copies of the attended maps for the offset-mode kernel (C = 256)
 
     def __call__(self, flow: torch.Tensor, extra_offset: torch.Tensor, small_patch: bool = False,
                  iter_mode: bool = False) -> torch.Tensor:
@@ -111,6 +112,11 @@ class AGCL:
                 self._scratch = torch.empty_like(self.fmap2)
             return ops.agcl_corr_iter(self.fmap1, self.fmap2, flow.float(), small_patch, self._scratch)
         f1, f2 = self.attended()
+        if f1.shape[1] == 256:  # the line-per-tap kernel is built for the 256-channel maps of the reference's configs
+            if self._nhwc is None:
+                self._nhwc = (ops.nchw_to_nhwc(f1), ops.nchw_to_nhwc(f2))
+            return ops.agcl_corr_offset(self._nhwc[0], self._nhwc[1], flow.float(), extra_offset.float(), small_patch,
+                                        channels_last=True)
         return ops.agcl_corr_offset(f1, f2, flow.float(), extra_offset.float(), small_patch)
 
     def attended(self):

@@ -134,6 +134,11 @@ int agcl_iter_launch(const float* f1, const float* f2, const float* flow, float*
 int agcl_offset_launch(const float* f1, const float* f2, const float* flow, const float* extra, float* out, int N, int C, int H,
                        int W, int small_patch, hipStream_t s, bool tiled);
 int agcl_check(const char* what, int N, int C, int H, int W);
+// offset mode on channels-last copies (N, H*W, C) of the maps (C == 256), and the copy itself
+bool agcl_offset_cl_supported(int C);
+int agcl_offset_cl_launch(const float* f1c, const float* f2c, const float* flow, const float* extra, float* out, int N, int C,
+                          int H, int W, int small_patch, hipStream_t s, bool tiled);
+int nchw_to_nhwc_launch(const float* in, float* out, int N, int C, int P, hipStream_t s);
 int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
                          float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
 bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius);

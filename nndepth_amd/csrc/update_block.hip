@@ -701,7 +701,8 @@ int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* pac
 }
 
 // CREStereo variant of the loop (cre_stereo/model.py:221-284): the correlation features come from the AGCL kernels
-// (iter mode: extra == nullptr, needs the `warped` scratch; offset mode otherwise), the state is a 2-channel flow
+// (iter mode: extra == nullptr, needs the `warped` scratch of B*C*H*W floats; offset mode otherwise: with a scratch of
+// 2*B*C*H*W floats the maps are copied channels-last once and sampled line by line), the state is a 2-channel flow
 // and iteration `it` searches a 3x3 window when it is odd, 1x9 when even.
 struct CreArgs {
     const float* f1;
@@ -774,9 +775,18 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
                            W, igev ? 1 : 0, lay);
         NND_LAUNCH_CHECK();
     }
+    // offset mode with a scratch: channels-last copies of the two maps, made once for all iterations of the stage
+    const bool cre_cl = cre && cre->extra && cre->warped && agcl_offset_cl_supported(cre->C) && !getenv("NND_AGCL_V1");
+    if (cre_cl) {
+        NND_TRY(nchw_to_nhwc_launch(cre->f1, cre->warped, B, cre->C, H * W, s));
+        NND_TRY(nchw_to_nhwc_launch(cre->f2, cre->warped + (int64_t)B * cre->C * H * W, B, cre->C, H * W, s));
+    }
     Act c = act(w.corr, p.d.cor_planes * n, p.d.cor_planes);
     auto lookup = [&](hipStream_t st_, int it) -> int {
         if (cre) {
+            if (cre->extra && cre_cl)
+                return agcl_offset_cl_launch(cre->warped, cre->warped + (int64_t)B * cre->C * H * W, w.flow, cre->extra, w.corr, B, cre->C,
+                                             H, W, it & 1, st_, true);
             if (cre->extra) return agcl_offset_launch(cre->f1, cre->f2, w.flow, cre->extra, w.corr, B, cre->C, H, W, it & 1, st_, true);
             return agcl_iter_launch(cre->f1, cre->f2, w.flow, cre->warped, w.corr, B, cre->C, H, W, it & 1, st_, true);
         }

@@ -356,11 +356,12 @@ class UpdateBlockEngine:
         if flow_init is not None:
             flow_init = flow_init.contiguous()
             _dev(flow_init)
+        need = fmap2.numel() if extra_offset is None else 2 * fmap2.numel()  # warped map / the two channels-last copies
         if extra_offset is not None:
             extra_offset = extra_offset.contiguous()
             _dev(extra_offset)
-        elif scratch is None or scratch.numel() < fmap2.numel():
-            scratch = torch.empty_like(fmap2)
+        if scratch is None or scratch.numel() < need:
+            scratch = torch.empty(need, dtype=torch.float32, device=d)
         with torch.cuda.device(d):
             check(lib.nnd_cre_stereo_refine(C.byref(self.desc), _p(self.packed), _p(fmap1), _p(fmap2), Cf, _p(extra_offset),
                                             _p(scratch), _p(net), _p(inp), _p(flow_init), _p(up), stride, _p(low),
@@ -492,19 +493,35 @@ def agcl_corr_iter(fmap1: torch.Tensor, fmap2: torch.Tensor, flow: torch.Tensor,
     return out
 
 
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> contiguous (N,H,W,C) copy (the channels-last maps of agcl_corr_offset)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_nchw_to_nhwc(_p(x), _p(out), N, C, H, W, _stream(d)), "nchw_to_nhwc")
+    return out
+
+
 def agcl_corr_offset(fmap1: torch.Tensor, fmap2: torch.Tensor, flow: torch.Tensor, extra_offset: torch.Tensor,
-                     small_patch: bool) -> torch.Tensor:
-    """cre_stereo/cost_volume.py:81-154 after the optional attention."""
+                     small_patch: bool, channels_last: bool = False) -> torch.Tensor:
+    """cre_stereo/cost_volume.py:81-154 after the optional attention.  channels_last: fmap1 / fmap2 are (N,H,W,C) copies
+    made by nchw_to_nhwc (C = 256): the line-per-tap kernel."""
     d = _dev(fmap1, fmap2, flow, extra_offset)
     fmap1, fmap2, flow, extra_offset = (t.contiguous() for t in (fmap1, fmap2, flow, extra_offset))
-    N, C, H, W = fmap1.shape
+    if channels_last:
+        N, H, W, C = fmap1.shape
+    else:
+        N, C, H, W = fmap1.shape
     if fmap2.shape != fmap1.shape or tuple(flow.shape) != (N, 2, H, W) or extra_offset.numel() != N * 18 * H * W:
         raise NndError(f"agcl_corr_offset: shapes {tuple(fmap1.shape)}, {tuple(fmap2.shape)}, flow {tuple(flow.shape)}, "
                        f"extra_offset {tuple(extra_offset.shape)}")
     out = torch.empty((N, 36, H, W), dtype=torch.float32, device=d)
+    fn = lib.nnd_agcl_corr_offset_nhwc if channels_last else lib.nnd_agcl_corr_offset
     with torch.cuda.device(d):
-        check(lib.nnd_agcl_corr_offset(_p(fmap1), _p(fmap2), _p(flow), _p(extra_offset), _p(out), N, C, H, W,
-                                       int(bool(small_patch)), _stream(d)), "agcl_corr_offset")
+        check(fn(_p(fmap1), _p(fmap2), _p(flow), _p(extra_offset), _p(out), N, C, H, W, int(bool(small_patch)), _stream(d)),
+              "agcl_corr_offset")
     return out
 
 

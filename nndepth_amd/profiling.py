@@ -95,12 +95,15 @@ def cre_rows(dev, sizes=((135, 240), (67, 120), (33, 60)), C: int = 256) -> List
         flow = torch.stack([-(6 + 4 * torch.sin(xx / 23) * torch.cos(yy / 17)), 0.7 * torch.sin(xx / 31 + yy / 13)], 0)[None].contiguous()
         off = torch.rand(B, 18, H, W, device=dev) * 2 - 1
         scratch = torch.empty_like(f2)
+        f1c, f2c = ops.nchw_to_nhwc(f1), ops.nchw_to_nhwc(f2)  # made once per cascade stage (10 iterations)
         alg = (2 * C + 2 + 36) * H * W * 4 / 1e6
         for sp in (False, True):
             rows.append(_row(f"agcl_corr_iter {H}x{W} small_patch={int(sp)}", time_us(lambda: ops.agcl_corr_iter(f1, f2, flow, sp, scratch)),
                              alg, "2 fmaps + flow read, 36 ch written"))
-            rows.append(_row(f"agcl_corr_offset {H}x{W} small_patch={int(sp)}", time_us(lambda: ops.agcl_corr_offset(f1, f2, flow, off, sp)),
-                             alg + 18 * H * W * 4 / 1e6, "2 fmaps + flow + 18 offsets read, 36 ch written"))
+            rows.append(_row(f"agcl_corr_offset {H}x{W} small_patch={int(sp)}",
+                             time_us(lambda: ops.agcl_corr_offset(f1c, f2c, flow, off, sp, channels_last=True)),
+                             alg + 18 * H * W * 4 / 1e6, "2 channels-last fmaps + flow + 18 offsets read, 36 ch written"))
+        rows.append(_row(f"nchw_to_nhwc {C}ch {H}x{W}", time_us(lambda: ops.nchw_to_nhwc(f1)), 2 * C * H * W * 4 / 1e6, "read + written once"))
         fl2, mask = f(B, 2, H, W), f(B, 576, H, W)
         rows.append(_row(f"convex_upsample r8 2ch {H}x{W}", time_us(lambda: ops.convex_upsample(fl2, mask, 8)),
                          (576 + 2 + 128) * H * W * 4 / 1e6, "576-ch mask + flow read, 2 x 64 px/px written"))

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../nndepth_amd/csrc"
 make -j8 >/dev/null
 mkdir -p ../../scripts/ablate
-OTHERS="conv_mfma.o corr1d.o agcl.o mask_upsample.o update_block.o encoder.o prepost.o loftr.o conv3d.o error.o"
+OTHERS="conv_mfma.o corr1d.o agcl.o mask_upsample.o update_block.o encoder.o prepost.o cascade.o loftr.o conv3d.o thin3d.o error.o"
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c conv_split.hip -o /tmp/cs_$name.o &&

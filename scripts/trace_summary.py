@@ -10,9 +10,14 @@ def short(n):
     if m: return "conv_split<" + m.group(1).replace(" ", "") + ">"
     m = re.search(r"(\w+_kernel)(<[^>]*>)?", n)
     return (m.group(1) + (m.group(2) or "")) if m else n[:30]
+# one segment per forward (it starts at its correlation build); the LAST segment that ran the bench line's arithmetic
+# (conv_split kernels when any forward used them: the exact-fp32 comparison leg runs after the timed steps)
 idx = [i for i, r in enumerate(rows) if "corr1d_build" in r["Kernel_Name"]]
-i0 = idx[-1]
-last = max(i for i, r in enumerate(rows) if "mask_upsample" in r["Kernel_Name"] or "convex_upsample" in r["Kernel_Name"])
+ends = idx[1:] + [len(rows)]
+segs = [(a, b) for a, b in zip(idx, ends)]
+with_split = [sg for sg in segs if any("conv_split" in r["Kernel_Name"] for r in rows[sg[0]:sg[1]])]
+i0, i1 = (with_split or segs)[-1]
+last = max(i for i in range(i0, i1) if "mask_upsample" in rows[i]["Kernel_Name"] or "convex_upsample" in rows[i]["Kernel_Name"])
 seq = [r for r in rows[i0:last + 1] if "nnd::" in r["Kernel_Name"]]
 mq = [r["Queue_Id"] for r in seq if "lookup" in r["Kernel_Name"]][0]
 g = collections.OrderedDict()

@@ -613,6 +613,51 @@ def test_cre_agcl_class_fullsize_vs_oracle(CR):
         assert (got.cpu() - exp).abs().max() <= 2e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 67, 120), (2, 64, 33, 60), (1, 32, 9, 8), (1, 256, 5, 4)])
+def test_cre_agcl_vector_kernels_equal_scalar_ones(monkeypatch, shape):
+    """Round-2 kernels against the round-1 ones on the same inputs (NND_AGCL_V1 selects the latter): the 4-pixel-per-lane
+    window correlation keeps the expression order -> bit-identical, image edges included (W = 4, 8: every run is an edge
+    run); the sampler's 8-byte tap pairs are the same values -> the warped map is bit-identical."""
+    from nndepth_amd import ops
+    torch.manual_seed(11)
+    N, C, H, W = shape
+    f1, f2 = torch.randn(N, C, H, W, device=DEV), torch.randn(N, C, H, W, device=DEV)
+    flow = torch.randn(N, 2, H, W, device=DEV) * 5
+    for sp in (False, True):
+        new = ops.agcl_corr_iter(f1, f2, flow, sp)
+        monkeypatch.setenv("NND_AGCL_V1", "1")
+        old = ops.agcl_corr_iter(f1, f2, flow, sp)
+        monkeypatch.delenv("NND_AGCL_V1")
+        assert torch.equal(new, old)
+
+
+@pytest.mark.parametrize("hw", [(67, 120), (135, 240), (7, 9)])
+def test_cre_agcl_offset_channels_last(gold, hw):
+    """Offset mode on channels-last copies (one wave per pixel, 16-lane DPP sums) against the planar kernel: same taps and
+    per-channel products, the 64-term channel sum in another order (<= 1e-6 at |f| ~ 1 randn inputs); against the imported
+    reference's golden (C = 256 case); and the copy kernel against permute()."""
+    from nndepth_amd import ops
+    torch.manual_seed(12)
+    H, W = hw
+    N, C = (2 if H < 100 else 1), 256
+    f1, f2 = torch.randn(N, C, H, W, device=DEV), torch.randn(N, C, H, W, device=DEV)
+    flow = torch.randn(N, 2, H, W, device=DEV) * 6
+    off = torch.rand(N, 18, H, W, device=DEV) * 4 - 2
+    a, b = ops.nchw_to_nhwc(f1), ops.nchw_to_nhwc(f2)
+    assert torch.equal(a, f1.permute(0, 2, 3, 1).contiguous())
+    for sp in (False, True):
+        got = ops.agcl_corr_offset(a, b, flow, off, sp, channels_last=True)
+        ref = ops.agcl_corr_offset(f1, f2, flow, off, sp)
+        assert (got - ref).abs().max().item() <= 1e-6
+    far = torch.full((N, 2, H, W), 1e4, device=DEV)
+    assert ops.agcl_corr_offset(a, b, far, off, False, channels_last=True).abs().max() == 0
+    g = gold("cre_agcl.npz")
+    g1, g2, gf, go = (t(g[f"c256_{k}"]).to(DEV) for k in ("f1", "f2", "flow", "off"))
+    for sp in (0, 1):
+        got = ops.agcl_corr_offset(ops.nchw_to_nhwc(g1), ops.nchw_to_nhwc(g2), gf, go, bool(sp), channels_last=True)
+        assert np.abs(got.cpu().numpy() - g[f"c256_off_sp{sp}"]).max() <= 3e-7
+
+
 def test_cre_agcl_properties():
     """Size-independent properties: zero flow + zero offsets at the window centre = plain per-group channel mean of
     f1*f2; linear in f1; samples far outside the image contribute exactly zero."""
