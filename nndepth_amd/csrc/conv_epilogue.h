@@ -260,6 +260,130 @@ __device__ __forceinline__ void conv_epilogue_c4(const ConvArgs& a, const f32x16
     }
 }
 
+// The c4 epilogue in two halves over a COMPACT register set, for a kernel with an intra-workgroup split-K exchange
+// (conv_split.hip): the wave stores NG = 4/ks groups of 4 registers per sub-tile, groups q0 .. q0+NG-1 (q0 = kj*NG is a
+// run-time value, used in addresses only).  `load` is issued before the exchange — the fragment registers are dead — and its
+// 16-B loads (per-pixel bias map, h, z) fly while the partial sums cross LDS; `store` takes the summed accumulators as
+// float4 cacc[pp][j].  Same per-element arithmetic, in the same order, as conv_epilogue_c4: bit-identical results.
+// All loads precede all stores of the wave (out0 may alias aux0).
+template <int P, int NG>
+struct EpiOpsC4 {
+    float4 bm[P][NG], hv[P][NG], zv[P][NG];  // bias (per channel or per pixel), h / residual, z
+    float4 scale4[NG];
+    long pix[P];  // already x4
+    bool pix_ok[P];
+};
+
+template <int P, int NG>
+__device__ __forceinline__ void epi_c4_load(const ConvArgs& a, const int cb, const int b, const int h2, const int q0,
+                                            const int (&ys)[P], const int (&xs)[P], EpiOpsC4<P, NG>& e) {
+    const long DP = a.ld.plane;
+    const int epi = a.epi;
+    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+    float4 bias4[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int co0 = cb * 32 + 8 * (q0 + j) + 4 * h2;
+        float bv[4], sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bv[i] = (!a.bmap && co0 + i < a.Cout) ? a.bias[co0 + i] : 0.f;
+            sv[i] = (epi == EPI_AFFINE && co0 + i < a.Cout) ? a.cscale[co0 + i] : 0.f;
+        }
+        bias4[j] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+        e.scale4[j] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+    }
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        const int y = ys[pp], x = xs[pp];
+        const bool pix_ok = (y < a.H && x < a.W);
+        const long pix = pix_ok ? pix_off(a.ld, y, x) : 0;
+        e.pix_ok[pp] = pix_ok;
+        e.pix[pp] = pix;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int co0 = cb * 32 + 8 * (q0 + j) + 4 * h2;
+            const bool ok = pix_ok && co0 + 3 < a.Cout;  // whole groups only
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            e.bm[pp][j] = bias4[j];
+            e.hv[pp][j] = zero;
+            e.zv[pp][j] = zero;
+            if (a.bmap && ok) e.bm[pp][j] = ld4(a.bmap + b * a.bmbs + (long)co0 * DP + pix);
+            if (epi == EPI_AFFINE) {
+                if (a.aux0 && ok) e.hv[pp][j] = ld4(a.aux0 + b * a.abs0 + (long)co0 * DP + pix);
+            } else if (epi == EPI_GRU_Q) {
+                if (ok) {
+                    e.hv[pp][j] = ld4(a.aux0 + b * a.abs0 + (long)co0 * DP + pix);
+                    e.zv[pp][j] = ld4(a.aux1 + b * a.abs1 + (long)co0 * DP + pix);
+                }
+            } else if (epi == EPI_GRU_ZR) {
+                if (ok && co0 >= a.hidden) e.hv[pp][j] = ld4(a.aux0 + b * a.abs0 + (long)(co0 - a.hidden) * DP + pix);
+            }
+        }
+    }
+}
+
+template <int P, int NG>
+__device__ __forceinline__ void epi_c4_store(const ConvArgs& a, const float4 (&cacc)[P][NG], const int cb, const int b, const int h2,
+                                             const int q0, const EpiOpsC4<P, NG>& e) {
+    const long DP = a.ld.plane;
+    const int epi = a.epi;
+    auto get = [](const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); };
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        if (!e.pix_ok[pp]) continue;
+        const long pix = e.pix[pp];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int co0 = cb * 32 + 8 * (q0 + j) + 4 * h2;
+            if (co0 >= a.Cout) continue;
+            const bool full = co0 + 3 < a.Cout;
+            float r0[4], r1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ac = get(cacc[pp][j], i);
+                const float v = ac + get(e.bm[pp][j], i);
+                float o0 = v, o1 = 0.f;
+                if (epi == EPI_RELU) o0 = fmaxf(v, 0.f);
+                else if (epi == EPI_SCALE) o0 = a.scale * v;
+                else if (epi == EPI_SIGMOID_RANGE) o0 = a.scale * (sigmoidf_(v) - 0.5f) * 2.0f;
+                else if (epi == EPI_AFFINE) {
+                    float y2 = fmaf(ac, get(e.scale4[j], i), get(e.bm[pp][j], i));
+                    if (a.flags & 4) y2 = y2 > 0.f ? y2 : a.scale * y2;
+                    if (a.flags & 1) y2 = fmaxf(y2, 0.f);
+                    if (a.aux0) y2 = get(e.hv[pp][j], i) + y2;
+                    if (a.flags & 2) y2 = fmaxf(y2, 0.f);
+                    o0 = y2;
+                } else if (epi == EPI_GRU_ZR) {
+                    const float sg = sigmoidf_(v);
+                    o0 = sg;
+                    o1 = sg * get(e.hv[pp][j], i);
+                } else if (epi == EPI_GRU_Q) {
+                    const float qq = tanhf_(v);
+                    o0 = fmaf(get(e.zv[pp][j], i), qq, (1.0f - get(e.zv[pp][j], i)) * get(e.hv[pp][j], i));
+                    o1 = o0;
+                }
+                r0[i] = o0;
+                r1[i] = o1;
+            }
+            const bool to1 = epi == EPI_GRU_ZR && co0 >= a.hidden;
+            float* d0 = to1 ? a.out1 + b * a.obs1 + (long)(co0 - a.hidden) * DP + pix : a.out0 + b * a.obs0 + (long)co0 * DP + pix;
+            const float* rr = to1 ? r1 : r0;
+            if (full) {
+                *reinterpret_cast<float4*>(d0) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                if (epi == EPI_GRU_Q && a.out1) *reinterpret_cast<float4*>(a.out1 + b * a.obs1 + (long)co0 * DP + pix) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co0 + i < a.Cout) {
+                        d0[i] = rr[i];
+                        if (epi == EPI_GRU_Q && a.out1) a.out1[b * a.obs1 + (long)co0 * DP + pix + i] = r1[i];
+                    }
+            }
+        }
+    }
+}
+
 // Epilogue of one wave: acc[pp] = the 32 (channel) x 32 (pixel) tile of sub-tile pp, this lane's pixel of it at (ys[pp], xs[pp]);
 // the wave stores registers [reg0, reg0 + nreg) (its share after an intra-workgroup split-K exchange; 0, 16 otherwise).
 template <int P>

@@ -326,11 +326,17 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
 
     NND_SSTAMP(2);
     NND_SCLOCK(6);
-    // ---- intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier); slice kj then
-    // owns registers [kj*16/ks, (kj+1)*16/ks) of the tile for the epilogue
+    int ys[P], xs[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        ys[pp] = ty0[pp] + r;
+        xs[pp] = tx0[pp] + c;
+    }
     float* red_all = reinterpret_cast<float*>(lds_raw);
     constexpr int TS = P * 1024;
-    if (ks > 1) {
+    // intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier): every wave leaves
+    // its partial tile, slice kj then owns registers [kj*16/ks, (kj+1)*16/ks) of the summed tile for the epilogue
+    auto exchange = [&]() {
         if (active) {
             float* red = red_all + (size_t)(cbi * ks + kj) * TS + lane;
 #pragma unroll
@@ -339,32 +345,73 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
                 for (int reg = 0; reg < 16; ++reg) red[pp * 1024 + reg * 64] = acc[pp][reg];
         }
         __syncthreads();
-    }
-    if (!active) return;
-    const int nreg = 16 / ks, reg0 = kj * nreg;
-    if (ks > 1) {
-        const float* red = red_all + (size_t)(cbi * ks) * TS + lane;
+    };
+    // c4 destination: NG = 4/ks register groups per sub-tile.  What the epilogue reads (per-pixel bias map, h, z) is requested
+    // BEFORE the exchange — the fragment registers are dead — and arrives while the partial sums cross LDS.
+    auto finish_c4 = [&](auto ng_c) {
+        constexpr int NG = decltype(ng_c)::value;  // == 4 / ks, ks = 2 or 4
+        const int q0 = kj * NG;
+        EpiOpsC4<P, NG> eo;
+#ifndef NND_SPLIT_NO_EPI
+        if (active) epi_c4_load<P, NG>(a, cb, b, h2, q0, ys, xs, eo);
+#endif
+        exchange();
+        if (!active) return;
+        float4 cacc[P][NG];
 #pragma unroll
         for (int pp = 0; pp < P; ++pp)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                if (reg < reg0 || reg >= reg0 + nreg) continue;
-                float sum = red[pp * 1024 + reg * 64];
-                for (int j = 1; j < ks; ++j) sum += red[(size_t)j * TS + pp * 1024 + reg * 64];
-                acc[pp][reg] = sum;
-            }
-    }
-    NND_SSTAMP(3);
-    int ys[P], xs[P];
+            for (int j = 0; j < NG; ++j) {
+                float v[4];
 #pragma unroll
-    for (int pp = 0; pp < P; ++pp) {
-        ys[pp] = ty0[pp] + r;
-        xs[pp] = tx0[pp] + c;
-    }
+                for (int i = 0; i < 4; ++i) {
+                    const float* red = red_all + (size_t)(cbi * ks) * TS + pp * 1024 + (4 * (q0 + j) + i) * 64 + lane;
+                    float sum = red[0];
+#pragma unroll
+                    for (int sl = 1; sl < 4 / NG; ++sl) sum += red[(size_t)sl * TS];
+                    v[i] = sum;
+                }
+                cacc[pp][j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        NND_SSTAMP(3);
 #ifdef NND_SPLIT_NO_EPI
-    if (acc[0][0] != 123.456f) return;
+        if (cacc[0][0].x != 123.456f) return;
 #endif
-    conv_epilogue<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
+        epi_c4_store<P, NG>(a, cacc, cb, b, h2, q0, eo);
+    };
+    if (a.ld.ci == 4) {
+        if (ks == 4) finish_c4(std::integral_constant<int, 1>{});
+        else if (ks == 2) finish_c4(std::integral_constant<int, 2>{});
+        else {  // no exchange to hide the loads behind
+            if (!active) return;
+            NND_SSTAMP(3);
+#ifdef NND_SPLIT_NO_EPI
+            if (acc[0][0] != 123.456f) return;
+#endif
+            conv_epilogue_c4<P>(a, acc, cb, b, h2, 0, 16, ys, xs);
+        }
+    } else {
+        if (ks > 1) exchange();
+        if (!active) return;
+        const int nreg = 16 / ks, reg0 = kj * nreg;
+        if (ks > 1) {
+            const float* red = red_all + (size_t)(cbi * ks) * TS + lane;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (reg < reg0 || reg >= reg0 + nreg) continue;
+                    float sum = red[pp * 1024 + reg * 64];
+                    for (int j = 1; j < ks; ++j) sum += red[(size_t)j * TS + pp * 1024 + reg * 64];
+                    acc[pp][reg] = sum;
+                }
+        }
+        NND_SSTAMP(3);
+#ifdef NND_SPLIT_NO_EPI
+        if (acc[0][0] != 123.456f) return;
+#endif
+        conv_epilogue_planar<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
+    }
 #ifdef NND_DBG_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
 #endif
