@@ -449,6 +449,14 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
     const long px_wgs = (long)cdiv(ntiles, SPLIT_P) * B;
     int force_ny = -1, force_ks = -1;
     if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d", &force_ny, &force_ks);
+    // Short K (Cin <= 64: at most 4 chunks, the encoder's first residual stage): a workgroup is mostly prologue, exchange and
+    // epilogue, so the best shape is the smallest one — no split K, all output-channel blocks in one workgroup (the patch is
+    // staged once), 6 two-wave workgroups per CU covering each other's fixed phases.  Measured, 64 -> 64 3x3 at 272x480x2
+    // (scripts/sweep_split_encoder.py): (ny,ks) = (1,1) 158 us | (1,2) 226 | (1,4) 326 | (2,1) 333; exact fp32 kernel 254.
+    if (L.nchunks <= 4 && force_ny <= 0 && force_ks <= 0 && L.ncb <= SPLIT_MAX_WAVES) {
+        force_ny = 1;
+        force_ks = 1;
+    }
     double best = 1e30;
     bool found = false;
     for (int ny = 1; ny <= L.ncb; ++ny) {

@@ -46,9 +46,6 @@ static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total, int 
     l.KH = d->KH; l.KW = d->KW; l.Cin = d->Cin; l.Cout = d->Cout; l.stride = d->stride;
     // the 1x1 projections stay on the streaming fp32 kernel (HBM-bound); 3x3 stride-1 layers may take the split kernel
     if (arith != 0 && (k11 || !conv_split_supported(d->KH, d->KW, d->Cin, d->stride, arith))) arith = 0;
-    // K = 64 * 9 is one super-chunk of the split kernel: prologue, exchange and epilogue with no K loop to hide behind.
-    // Measured at 272x480x2 (layer1): 238 us split vs 218 us exact fp32; from 96 channels up the split kernel wins (97 vs 138).
-    if (arith != 0 && d->Cin < 96) arith = 0;
     l.arith = arith;
     l.CI_T = arith ? 16 : conv_ci_t(d->KH, d->KW, d->Cin, d->stride, d->Cout);
     l.nchunks = cdiv(d->Cin, l.CI_T);
