@@ -244,7 +244,9 @@ __device__ __forceinline__ void conv_epilogue_c4(const ConvArgs& a, const f32x16
             // EPI_GRU_ZR: channel groups below `hidden` are z (out0), the others r*h (out1, channel - hidden)
             const bool to1 = epi == EPI_GRU_ZR && co0 >= a.hidden;
             float* d0 = to1 ? a.out1 + b * a.obs1 + (long)(co0 - a.hidden) * DP + pix : a.out0 + b * a.obs0 + (long)co0 * DP + pix;
-            const float* rr = to1 ? r1 : r0;
+            float rr[4];  // element-wise select: a pointer select between the two arrays would put both in scratch memory
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rr[i] = to1 ? r1[i] : r0[i];
             if (full) {
                 *reinterpret_cast<float4*>(d0) = make_float4(rr[0], rr[1], rr[2], rr[3]);
                 if (epi == EPI_GRU_Q && a.out1) *reinterpret_cast<float4*>(a.out1 + b * a.obs1 + (long)co0 * DP + pix) = make_float4(r1[0], r1[1], r1[2], r1[3]);
@@ -368,7 +370,9 @@ __device__ __forceinline__ void epi_c4_store(const ConvArgs& a, const float4 (&c
             }
             const bool to1 = epi == EPI_GRU_ZR && co0 >= a.hidden;
             float* d0 = to1 ? a.out1 + b * a.obs1 + (long)(co0 - a.hidden) * DP + pix : a.out0 + b * a.obs0 + (long)co0 * DP + pix;
-            const float* rr = to1 ? r1 : r0;
+            float rr[4];  // element-wise select: a pointer select between the two arrays would put both in scratch memory
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rr[i] = to1 ? r1[i] : r0[i];
             if (full) {
                 *reinterpret_cast<float4*>(d0) = make_float4(rr[0], rr[1], rr[2], rr[3]);
                 if (epi == EPI_GRU_Q && a.out1) *reinterpret_cast<float4*>(a.out1 + b * a.obs1 + (long)co0 * DP + pix) = make_float4(r1[0], r1[1], r1[2], r1[3]);

@@ -453,43 +453,61 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
     // epilogue, so the best shape is the smallest one — no split K, all output-channel blocks in one workgroup (the patch is
     // staged once), 6 two-wave workgroups per CU covering each other's fixed phases.  Measured, 64 -> 64 3x3 at 272x480x2
     // (scripts/sweep_split_encoder.py): (ny,ks) = (1,1) 158 us | (1,2) 226 | (1,4) 326 | (2,1) 333; exact fp32 kernel 254.
+    bool rule = false;
     if (L.nchunks <= 4 && force_ny <= 0 && force_ks <= 0 && L.ncb <= SPLIT_MAX_WAVES) {
         force_ny = 1;
         force_ks = 1;
+        rule = true;
     }
-    double best = 1e30;
-    bool found = false;
-    for (int ny = 1; ny <= L.ncb; ++ny) {
-        if (L.ncb % ny != 0 || (force_ny > 0 && ny != force_ny)) continue;
-        const int wco = L.ncb / ny;
-        for (int ks : {1, 2, 4}) {
-            if (force_ks > 0 && ks != force_ks) continue;
-            const int waves = wco * ks;
-            if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
-            if (c1 > 0 && c0 % (ks * 16) != 0) continue;
-            const int nu = cdiv(SPLIT_P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread (2 built, 4 for 1-2 waves)
-            if (nu > 4) continue;
-            size_t lds = (size_t)2 * ks * SPLIT_P * subb;
-            const size_t red = ks > 1 ? (size_t)waves * SPLIT_P * 4096 : 0;
-            if (red > lds) lds = red;
-            if (lds > 160 * 1024) continue;
-            int wg_per_cu = (int)((160 * 1024) / lds);
-            if (wg_per_cu > SPLIT_MAX_WAVES / waves) wg_per_cu = SPLIT_MAX_WAVES / waves;
-            if (wg_per_cu < 1) wg_per_cu = 1;
-            const double rounds = std::ceil((double)px_wgs * ny / (256.0 * wg_per_cu));
-            const double simd_waves = std::ceil(waves * wg_per_cu / 4.0);
-            double t = rounds * simd_waves * cdiv(L.nchunks, ks);
-            t *= 1.0 + 0.03 * (ks - 1);       // split-K exchange
-            t *= 1.0 + 0.02 * (4 - (wco < 4 ? wco : 4));  // fewer waves share one staged patch
-            if (nu > 2) t *= 1.2;                          // register-heavy staging variant
-            if (t < best) {
-                best = t;
-                *out = {ny, wco, ks, ntiles, tiles_x, nu <= 2 ? 2 : 4, lds};
-                found = true;
+    // Many workgroup columns (>= 448: 136x240 maps, batch 8 at KITTI size, the encoder's first stages): the chip is filled
+    // several times over, so no split K (no exchange, small LDS, several workgroups per CU covering each other's prologue and
+    // epilogue); with a long K (>= 16 chunks) at most 4 output-channel blocks per workgroup, with a short K all of them (the
+    // patch staging then dominates and is done once).  Measured with scripts/sweep_split.py at 48x156 batch 8 against the
+    // cost model below: zr 312 -> 280 us, q 202 -> 165, convc2 412 -> 379, conv 246 -> 228 (profiles/r02_split_wg_shape_sweep.txt).
+    if (!rule && px_wgs >= 448 && force_ny <= 0 && force_ks <= 0 && L.ncb <= SPLIT_MAX_WAVES) {
+        rule = true;
+        force_ks = 1;
+        force_ny = 1;
+        if (L.nchunks >= 16)
+            while (force_ny < L.ncb && (L.ncb % force_ny != 0 || L.ncb / force_ny > 4)) ++force_ny;
+    }
+    auto search = [&](int f_ny, int f_ks) {
+        double best = 1e30;
+        bool found = false;
+        for (int ny = 1; ny <= L.ncb; ++ny) {
+            if (L.ncb % ny != 0 || (f_ny > 0 && ny != f_ny)) continue;
+            const int wco = L.ncb / ny;
+            for (int ks : {1, 2, 4}) {
+                if (f_ks > 0 && ks != f_ks) continue;
+                const int waves = wco * ks;
+                if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
+                if (c1 > 0 && c0 % (ks * 16) != 0) continue;
+                const int nu = cdiv(SPLIT_P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread (2 built, 4 for 1-2 waves)
+                if (nu > 4) continue;
+                size_t lds = (size_t)2 * ks * SPLIT_P * subb;
+                const size_t red = ks > 1 ? (size_t)waves * SPLIT_P * 4096 : 0;
+                if (red > lds) lds = red;
+                if (lds > 160 * 1024) continue;
+                int wg_per_cu = (int)((160 * 1024) / lds);
+                if (wg_per_cu > SPLIT_MAX_WAVES / waves) wg_per_cu = SPLIT_MAX_WAVES / waves;
+                if (wg_per_cu < 1) wg_per_cu = 1;
+                const double rounds = std::ceil((double)px_wgs * ny / (256.0 * wg_per_cu));
+                const double simd_waves = std::ceil(waves * wg_per_cu / 4.0);
+                double t = rounds * simd_waves * cdiv(L.nchunks, ks);
+                t *= 1.0 + 0.03 * (ks - 1);       // split-K exchange
+                t *= 1.0 + 0.02 * (4 - (wco < 4 ? wco : 4));  // fewer waves share one staged patch
+                if (nu > 2) t *= 1.2;                          // register-heavy staging variant
+                if (t < best) {
+                    best = t;
+                    *out = {ny, wco, ks, ntiles, tiles_x, nu <= 2 ? 2 : 4, lds};
+                    found = true;
+                }
             }
         }
-    }
-    return found;
+        return found;
+    };
+    if (search(force_ny, force_ks)) return true;
+    return rule && search(-1, -1);  // the regime rule's shape does not exist for this layer: the cost model decides
 }
 
 template <int KH, int KW, int NS, int NU>

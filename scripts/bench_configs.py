@@ -15,15 +15,19 @@ from nndepth_amd import weightgen  # noqa: E402
 dev = "cuda:0"
 
 
-def timeit(fn, reps, warm=2):
+def timeit(fn, reps, warm=3):
+    """Median wall time of `reps` synchronised calls, ms (a one-off allocator hiccup in one rep does not move it)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def main():
@@ -36,23 +40,25 @@ def main():
         weightgen.fill_module_(m)
         m = m.to(dev).eval()
         f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(2, 8, 384, 1248))
-        ms = timeit(lambda: m(f1, f2), 5)
+        ms = timeit(lambda: m(f1, f2), 7)
         print(f"config 4 per-GPU work [{ar}]: RAFT-Stereo 8 x 384x1248, 32 iters: {ms:.1f} ms / batch = {8e3 / ms:.1f} pairs/s", flush=True)
         del m, f1, f2
+        torch.cuda.empty_cache()
         m = CREStereoBase(iters=20, arithmetic=ar)
         weightgen.fill_module_(m)
         m = m.to(dev).eval()
         f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(3, 1, 1080, 1920))
-        ms = timeit(lambda: m(f1, f2), 5)
-        ms2 = timeit(lambda: two_stage_forward(m, f1, f2), 5)
+        ms = timeit(lambda: m(f1, f2), 7)
+        ms2 = timeit(lambda: two_stage_forward(m, f1, f2), 7)
         print(f"config 5 per-GPU work [{ar}]: CREStereo 1080x1920, 20 iters: cascade {ms:.1f} ms / pair, 2-stage harness {ms2:.1f} ms / pair", flush=True)
         del m, f1, f2
+        torch.cuda.empty_cache()
         for B in (1, 8):
             m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=32, hidden_dim=64, context_dim=64, arithmetic=ar)
             weightgen.fill_module_(m, "igev.")
             m = m.to(dev).eval()
             f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(4, B, 544, 960))
-            ms = timeit(lambda: m(f1, f2), 3, warm=1)
+            ms = timeit(lambda: m(f1, f2), 5, warm=2)
             print(f"config 3 [{ar}]: IGEV 544x960 batch {B}, 32 iters (tiny backbone): {ms:.1f} ms / batch = {B * 1e3 / ms:.2f} pairs/s; "
                   f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
             del m, f1, f2

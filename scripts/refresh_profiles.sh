@@ -39,3 +39,13 @@ python scripts/bench_configs.py > $O/other_configs.txt 2>&1 || true
 python scripts/prof_regulariser_layers.py > $O/igev_regulariser_layers.txt 2>&1 || true
 python scripts/prof_split.py > $O/split_vs_fp32_68x120.txt 2>&1 || true
 python scripts/prof_split.py 136 240 > $O/split_vs_fp32_136x240.txt 2>&1 || true
+# CREStereo 1080x1920 cascade: per-kernel totals of 4 forwards; encoder timeline of one bf16x3 forward of the bench
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cre -o c -- python scripts/prof_cre_kernels.py bf16x3 3 > $O/cre.log 2>&1 || true
+python scripts/kernel_stats_top.py $O/cre 30 > $O/cre_kernels.txt 2>&1 || true
+tail -1 $O/cre.log >> $O/cre_kernels.txt
+find $O/cre -name "*kernel_trace.csv" -delete
+rocprofv3 --kernel-trace --output-format csv -d $O/enc -o b -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-hbm-group --no-roofline > /dev/null 2>&1 || true
+python scripts/trace_encoder.py $O/enc 2 > $O/encoder_timeline_bf16x3.txt 2>&1 || true
+python scripts/trace_encoder.py $O/enc -1 > $O/encoder_timeline_fp32.txt 2>&1 || true
+find $O/enc -name "*kernel_trace.csv" -delete
+python scripts/sweep_split_encoder.py > $O/split_encoder_shapes.txt 2>&1 || true
