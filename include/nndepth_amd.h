@@ -15,11 +15,9 @@
  *   - return value: 0 on success, negative nnd_status on failure (never throws);
  *     nnd_last_error() gives a thread-local message for the last failure;
  *   - threading: every entry point may be called concurrently from several host threads as long as the calls
- *     use distinct streams and distinct output / workspace buffers.  The only mutable global state is a
- *     mutex-guarded per-device pool of idle low-priority side streams: each nnd_*_stereo_refine call draws one
- *     stream from it, creates its own two fork/join events, and joins the side stream back into the caller's
- *     stream before returning — on error returns too — so no work that touches the caller's buffers is ever left
- *     un-ordered behind `stream`;
+ *     use distinct streams and distinct output / workspace buffers.  The library keeps no mutable global state:
+ *     every kernel of a call — the fused loops' too — is enqueued on the caller's `stream` and nowhere else
+ *     (rounds 1-2 ran one branch of the loop on an internal side stream; measured equal, removed);
  *   - diagnostic environment switches (read per call; they select between kernels that the parity tests prove
  *     equivalent, never a non-HIP path): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
  *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
@@ -378,10 +376,9 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed_dev,
                      int B, int H, int W, int which, int reps, void* stream,
                      float* ms_out, double* flops_out);
 /* The same conv timed where it runs in production: inside the fused RAFT-Stereo loop (arguments as
- * nnd_raft_stereo_refine, only the last up_disp is kept), bracketed by hipEvents on `stream` in every iteration while the
- * flow branch shares the chip from the side stream.  *ms_out = average over iterations 2..iters (event-to-event, so it
+ * nnd_raft_stereo_refine, only the last up_disp is kept), bracketed by hipEvents on `stream` in every iteration.  *ms_out = average over iterations 2..iters (event-to-event, so it
  * includes the launch gap in front of the kernel).  Synchronises `stream`.  `which` must be one of the stand-alone
- * launches of the recurrence (not convc1 / convf2 / mask.2, which are fused or on the side stream).                    */
+ * launches of the loop (not convc1 / mask.2, which are fused into their neighbours).                    */
 int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed_dev, const float* pyramid,
                           int num_levels, int radius, const float* net, const float* inp, float* up_out,
                           float* workspace, int B, int H, int W, int rate, int iters, int which, void* stream,

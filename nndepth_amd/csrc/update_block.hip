@@ -9,14 +9,13 @@
 // torch.cat is never materialised: tensors that the reference concatenates live side by side in one
 // workspace buffer (hx = [h | inp | motion | flow], cf = [cor | flo], fm = [flow_head.conv1 | mask.0]) and the
 // convolutions write straight into their channel slice.  convz/convr are packed as one 2*hidden-channel
-// conv whose epilogue emits z and r*h; convq's epilogue does the GRU blend in place.  In the fused loop the
-// flow branch (convf1 -> convf2) runs on a side stream beside the critical path (see ForkJoin / enqueue_refine).
+// conv whose epilogue emits z and r*h; convq's epilogue does the GRU blend in place.  The fused loops enqueue every
+// kernel of every iteration on the caller's stream (enqueue_refine).
 #include "common.h"
 #include "layout.h"
 
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <vector>
 
 namespace nnd {
@@ -80,8 +79,7 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->L[C_C2] = mk(3, 3, 256, 192, &off, ar(C_C2));
     p->f1_w = off; off += (int64_t)128 * fc * 49;
     p->f1_b = off; off += 128;
-    p->L[C_F2] = mk(3, 3, 128, 64, &off);  // side stream, beside convc2: stays on the fp32 kernel, whose small workgroups fit
-                                           // next to the one-per-CU workgroups of the split kernel (in-loop convc2 71 -> see DESIGN §4)
+    p->L[C_F2] = mk(3, 3, 128, 64, &off);  // stays on the exact kernel: 20 us there, 22-24 us on the split kernel (K = 8 chunks, Cout 64)
     p->L[C_CV] = mk(3, 3, 256, hid - fc, &off, ar(C_CV));
     for (int pass = 0; pass < (p->sep ? 2 : 1); ++pass) {
         const int kh = p->sep ? (pass == 0 ? 1 : 5) : 3, kw = p->sep ? (pass == 0 ? 5 : 1) : 3;
@@ -147,9 +145,8 @@ __global__ void __launch_bounds__(256) convf1_kernel(const float* __restrict__ f
                                                      const float* __restrict__ bias, float* __restrict__ out, long obs,
                                                      int H, int W, int tiles_x, Lay lay) {
     __shared__ float patch[FC][14][40];
-    // the workgroup's 16 x FC*49 weights, read back as LDS broadcasts.  (Round 1 read them through the scalar cache as SGPR
-    // operands: 16 dependent s_load batches per thread, each a scalar-cache miss, made this 0.1-GFLOP kernel take 26 us on the
-    // side stream, where it slowed the concurrent convc2 from 48 to 63 us.)
+    // the workgroup's 16 x FC*49 weights, read back as LDS broadcasts (round 1 read them through the scalar cache as SGPR
+    // operands: 16 dependent s_load batches per thread, each a scalar-cache miss)
     __shared__ __attribute__((aligned(16))) float wl[16 * (FC * 49 + 3)];
     constexpr int WS = FC * 49 + 3;  // row stride: multiple of 4 floats
     const int tid = threadIdx.x;
@@ -480,64 +477,6 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     return debug_sync("flow_head.conv2", s);
 }
 
-// Fork / join state of ONE fused-loop call.  The flow branch of the motion encoder runs on a low-priority side stream
-// beside the recurrence on the caller's stream; all cross-stream edges are explicit events.  Everything here is per call:
-// the two events are created by the call and destroyed when it returns, and the side stream is drawn from a per-device pool
-// (the only mutable global state of the library, mutex-guarded) and handed back after the join — so host threads that drive
-// distinct caller streams of one device never share a side stream or an event while they enqueue (include/nndepth_amd.h,
-// threading contract).  The destructor joins the side stream back into the caller's stream on EVERY exit path, error
-// returns included: nothing that references the caller's workspace is left un-ordered behind the caller's stream.
-struct StreamPool {
-    std::mutex mu;
-    std::vector<hipStream_t> idle[16];
-};
-static StreamPool& stream_pool() {
-    static StreamPool p;
-    return p;
-}
-struct ForkJoin {
-    hipStream_t caller = nullptr, a = nullptr;  // a: flow branch (convf1, convf2)
-    hipEvent_t f2 = nullptr, adv = nullptr;
-    int dev = -1;
-    bool forked = false;
-    int open(hipStream_t s) {
-        caller = s;
-        // the device that owns the caller's stream (the NULL stream belongs to the current device)
-        if (s == nullptr || hipStreamGetDevice(s, &dev) != hipSuccess) NND_HIP_CHECK(hipGetDevice(&dev));
-        NND_REQUIRE(dev >= 0 && dev < 16, "refine: device ordinal %d outside the side-stream pool", dev);
-        {
-            StreamPool& p = stream_pool();
-            std::lock_guard<std::mutex> lock(p.mu);
-            if (!p.idle[dev].empty()) {
-                a = p.idle[dev].back();
-                p.idle[dev].pop_back();
-            }
-        }
-        if (!a) {
-            // lowest priority: the side branch only fills the bubbles of the recurrence on the caller's stream
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-            NND_HIP_CHECK(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, least));
-        }
-        NND_HIP_CHECK(hipEventCreateWithFlags(&f2, hipEventDisableTiming));
-        NND_HIP_CHECK(hipEventCreateWithFlags(&adv, hipEventDisableTiming));
-        return NND_OK;
-    }
-    ~ForkJoin() {
-        if (a && forked && f2) {  // join: whatever is still queued on the side stream precedes the caller's next work
-            if (hipEventRecord(f2, a) == hipSuccess) (void)hipStreamWaitEvent(caller, f2, 0);
-        }
-        // destroying an event with a pending record / wait is legal: its resources are released once it completes
-        if (f2) (void)hipEventDestroy(f2);
-        if (adv) (void)hipEventDestroy(adv);
-        if (a) {
-            StreamPool& p = stream_pool();
-            std::lock_guard<std::mutex> lock(p.mu);
-            p.idle[dev].push_back(a);
-        }
-    }
-};
-
 // One application of the update block on workspace state: expects h/inp/flow already in w.hx,
 // `flow` = (B,fc,H,W) dense.  Writes new h into w.hx[0:hid], delta, and (optionally) the mask.  Single stream.
 static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr, const float* flow, float* mask_dst,
@@ -796,18 +735,17 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     // per-pair context terms of the GRU convs (inp is constant over the iterations)
     for (int id : {(int)C_ZR1C, (int)C_Q1C, (int)C_ZR2C, (int)C_Q2C})
         if (p.sep || id < C_ZR2C) NND_TRY(run_conv(p, packed, w, id, c, nullptr, nullptr, B, H, W, s));
-    // Per-iteration schedule over two streams (M = caller's stream carries the recurrence):
-    //   M: lookup (+convc1), convc2, [f2] conv, zr1, q1, zr2, q2, flow_head.conv1+mask.0, flow_head.conv2+advance ->(adv),
-    //      mask.2 + convex upsample (fused)
-    //   A: (adv) convf1, convf2 ->(f2)                              flow branch of the motion encoder
-    // Measured on MI355X at 544x960 (ms per pair): M+A 17.6 | M+A+B (mask branch on a third stream, which needs a
-    // double-buffered copy of h and 3 more event operations on M per iteration) 18.0 | everything on M 17.7 | M only,
-    // captured into a hipGraph 17.6 | the 3-stream DAG as a hipGraph 34.  The kernels of one iteration already fill the
-    // chip (sum of the stand-alone kernel times = in-loop time), so more streams buy no overlap and every event
-    // record / wait on M costs a ~7 us bubble.
-    ForkJoin fj;
-    NND_TRY(fj.open(s));
-    ForkJoin* st = &fj;
+    // Per-iteration schedule, all on the caller's stream:
+    //   convf1, convf2 (flow branch of the motion encoder), lookup (+convc1), convc2, conv, zr1, q1, zr2, q2,
+    //   flow_head.conv1+mask.0, flow_head.conv2+advance, mask.2 + convex upsample (fused)
+    // Rounds 1-2 ran the flow branch on a low-priority side stream beside lookup / convc2 (per-call fork/join events).
+    // Measured on MI355X, same box, ms per 544x960 pair: side stream 11.79, in line 11.82 (KITTI batch 8 70.5 / 71.0,
+    // CREStereo 39.8 / 39.9, IGEV batch 8 190.1 / 190.5): the overlap it bought (convc2 61 us beside the branch instead
+    // of 44 + 20 + 20 in line) is what its 2 event records + 2 waits per iteration cost in launch gaps (0.47 -> 0.01 ms
+    // per pair).  Equal speed, so the version without cross-stream state stays: nothing to join on error paths, no
+    // shared stream pool, and the in-loop time of a kernel is its stand-alone time.  Earlier measurements (round 1, ms
+    // per pair): a third stream for the mask branch 18.0 vs 17.6 | the linear schedule as a hipGraph 17.6 vs 17.6 |
+    // the 3-stream DAG as a hipGraph 34.
     const bool no_fuse_up = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;  // read per call: the parity tests toggle these
     const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
@@ -819,13 +757,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         probe_mark(id, s);
         return rc_;
     };
-    NND_HIP_CHECK(hipEventRecord(st->adv, s));
-    st->forked = true;
     for (int it = 0; it < iters; ++it) {
-        NND_HIP_CHECK(hipStreamWaitEvent(st->a, st->adv, 0));
-        NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, st->a));
-        NND_TRY(run_conv(p, packed, w, C_F2, c, nullptr, nullptr, B, H, W, st->a));
-        NND_HIP_CHECK(hipEventRecord(st->f2, st->a));
+        NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, s));
+        NND_TRY(loop_conv(C_F2));
         if (fused_lk && interleaved && igev_lookup_convc1_il_supported(groups, num_levels, radius)) {  // IGEV over the group-interleaved copy of both pyramids
             NND_TRY(igev_lookup_convc1_il_launch(interleaved, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W, num_levels,
                                                  radius, s, ws_c4()));
@@ -837,7 +771,6 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
         }
         NND_TRY(loop_conv(C_C2));
-        NND_HIP_CHECK(hipStreamWaitEvent(s, st->f2, 0));
         NND_TRY(loop_conv(C_CV));
         NND_TRY(loop_conv(C_ZR1X));
         NND_TRY(loop_conv(C_Q1X));
@@ -847,7 +780,6 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         }
         NND_TRY(loop_conv(C_FHM));  // flow_head.conv1 and mask.0 in one launch
         NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
-        NND_HIP_CHECK(hipEventRecord(st->adv, s));  // the flow is final: stream A may start the next flow branch
         float* up_it = up_out + (int64_t)it * up_iter_stride;
         if (fused_up) {  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
             NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow, up_it, B, H, W, rate, s,
@@ -857,7 +789,6 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(convex_upsample_launch(w.flow, w.mask, up_it, B, fc, H, W, rate, s, true));
         }
     }
-    // (the side stream is joined back into `s` by ~ForkJoin; its last result was consumed already)
     if (low_out) NND_TRY(from_tiled(w.flow, fc * n, low_out, B, fc, H, W, s));
     if (net_out) NND_TRY(from_tiled(w.hx, hxC * n, net_out, B, hid, H, W, s, 0, ws_c4()));
     return NND_OK;
@@ -1019,7 +950,7 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, flo
 extern "C" int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
                                      int radius, const float* net, const float* inp, float* up_out, float* workspace, int B, int H,
                                      int W, int rate, int iters, int which, void* stream, float* ms_out) {
-    NND_REQUIRE(ms_out && which >= 0 && which < C_LOOP_COUNT && which != C_C1 && which != C_F2 && which != C_M2 && iters > 0,
+    NND_REQUIRE(ms_out && which >= 0 && which < C_LOOP_COUNT && which != C_C1 && which != C_M2 && iters > 0,
                 "profile_loop_conv: conv %d is not a stand-alone launch of the recurrence", which);
     LoopProbe probe;
     probe.which = which;

@@ -388,8 +388,7 @@ class UpdateBlockEngine:
 
 
     def profile_loop_conv(self, which: int, pyr, num_levels: int, radius: int, net, inp, rate: int, iters: int) -> float:
-        """-> avg ms of conv `which` INSIDE the fused RAFT-Stereo loop (hipEvents on the launch stream in every iteration,
-        the flow branch sharing the chip from the side stream as in production)."""
+        """-> avg ms of conv `which` INSIDE the fused RAFT-Stereo loop (hipEvents on the launch stream in every iteration)."""
         d = _dev(pyr, net, inp, self.packed)
         net, inp = net.contiguous(), inp.contiguous()
         B, _, H, W = net.shape

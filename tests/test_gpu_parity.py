@@ -310,7 +310,7 @@ def test_batch_consistency(raft_sd):
 
 def test_two_host_threads_on_two_streams_equal_serial(raft_sd):
     """Threading contract of include/nndepth_amd.h: host threads driving distinct streams (and distinct buffers) of one
-    device may call nnd_raft_stereo_refine concurrently — every call owns its fork/join events and its side stream.
+    device may call nnd_raft_stereo_refine concurrently — the library keeps no global state, every launch goes to the caller's stream.
     Two threads x 6 forwards on their own streams must reproduce the serial results bit for bit."""
     import threading
     from nndepth_amd import weightgen
