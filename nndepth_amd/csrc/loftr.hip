@@ -97,27 +97,55 @@ __global__ void __launch_bounds__(256) attn_msg_kernel(const float* __restrict__
     }
 }
 
-// y[n,:,p] = LayerNorm_C(x[n,:,p]) * gamma + beta (+ res[n,:,p]); thread = pixel (coalesced over pixels), two passes over C
+// y[n,:,p] = LayerNorm_C(x[n,:,p]) * gamma + beta (+ res[n,:,p]).  Workgroup = 32 pixels x 8 channel slices: a half-wave reads
+// 32 consecutive pixels of a channel (one 128-B line), a thread keeps its C/8 values in registers (C <= 8*LN_MAXC) so x is read
+// once; mean and variance (two-pass, as torch) meet in LDS.  The maps here have a few thousand pixels: one thread per pixel
+// walking all C channels three times (round 1) put 8 workgroups on the chip and took 168 us at 33x60x2, C = 256.
+constexpr int LN_MAXC = 64;
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, long bs, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ res, long rbs,
                                                         float* __restrict__ y, long ybs, int C, int L, float eps) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= L) return;
-    const int n = blockIdx.y;
-    const float* xb = x + (long)n * bs + p;
+    __shared__ float part[8][33];
+    const int px = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + px, n = blockIdx.y;
+    const bool ok = p < L;
+    const int per = (C + 7) / 8, c0 = sl * per, c1 = min(c0 + per, C);
+    const float* xb = x + (long)n * bs + (ok ? p : 0);
+    float v[LN_MAXC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        v[i] = (c0 + i < c1) ? xb[(long)(c0 + i) * L] : 0.f;
+        sum += v[i];
+    }
+    part[sl][px] = sum;
+    __syncthreads();
     float mean = 0.f;
-    for (int c = 0; c < C; ++c) mean += xb[(long)c * L];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mean += part[j][px];
     mean /= (float)C;
+    __syncthreads();
     float var = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float d = xb[(long)c * L] - mean;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const float d = (c0 + i < c1) ? v[i] - mean : 0.f;
         var = fmaf(d, d, var);
     }
+    part[sl][px] = var;
+    __syncthreads();
+    var = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) var += part[j][px];
     const float rstd = 1.0f / sqrtf(var / (float)C + eps);
-    for (int c = 0; c < C; ++c) {
-        float v = (xb[(long)c * L] - mean) * rstd * gamma[c] + beta[c];
-        if (res) v = res[(long)n * rbs + (long)c * L + p] + v;
-        y[(long)n * ybs + (long)c * L + p] = v;
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = c0 + i;
+        if (c < c1) {
+            float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            if (res) o = res[(long)n * rbs + (long)c * L + p] + o;
+            y[(long)n * ybs + (long)c * L + p] = o;
+        }
     }
 }
 
@@ -147,6 +175,7 @@ static ConvLayer lin(int Cout, int Cin, int64_t* off, int64_t* base) {
 static int make_loftr_plan(int d_model, int nhead, LoftrPlan* p) {
     NND_REQUIRE(d_model > 0 && nhead > 0 && d_model % nhead == 0 && d_model / nhead == 32,
                 "loftr: d_model %d / nhead %d: the attention kernels are built for 32 channels per head", d_model, nhead);
+    NND_REQUIRE(d_model <= 8 * LN_MAXC, "loftr: d_model %d above the LayerNorm kernel's %d channels", d_model, 8 * LN_MAXC);
     p->C = d_model; p->nhead = nhead;
     int64_t off = 0;
     p->q = lin(d_model, d_model, &off, &p->bq);
@@ -250,13 +279,13 @@ int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed, const f
     NND_LAUNCH_CHECK();
     // merge + norm1 (q is free again: holds the merged message, then its normalised version in place)
     NND_TRY(run_lin(p.merge, packed + p.bm, msg, C, nullptr, 0, bs, 0, q, bs, false, N, H, W, s));
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, s, (const float*)q, (long)bs, packed + p.ln1,
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(L, 32), N), dim3(256), 0, s, (const float*)q, (long)bs, packed + p.ln1,
                        packed + p.ln1 + C, (const float*)nullptr, 0L, q, (long)bs, C, L, 1e-5f);
     NND_LAUNCH_CHECK();
     // mlp on the virtual concat [x | message]
     NND_TRY(run_lin(p.mlp0, packed + p.b0, x, C, q, C, bs, bs, t, 2 * bs, true, N, H, W, s));
     NND_TRY(run_lin(p.mlp2, packed + p.b2, t, 2 * C, nullptr, 0, 2 * bs, 0, k, bs, false, N, H, W, s));
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(L, 256), N), dim3(256), 0, s, (const float*)k, (long)bs, packed + p.ln2,
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(L, 32), N), dim3(256), 0, s, (const float*)k, (long)bs, packed + p.ln2,
                        packed + p.ln2 + C, x, (long)bs, out, (long)bs, C, L, 1e-5f);
     NND_LAUNCH_CHECK();
 #undef NND_TRY

@@ -27,6 +27,7 @@ def timeit(fn, reps, warm=3):
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
+    timeit.best = ts[0]
     return ts[len(ts) // 2]
 
 
@@ -48,9 +49,10 @@ def main():
         weightgen.fill_module_(m)
         m = m.to(dev).eval()
         f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(3, 1, 1080, 1920))
-        ms = timeit(lambda: m(f1, f2), 7)
-        ms2 = timeit(lambda: two_stage_forward(m, f1, f2), 7)
-        print(f"config 5 per-GPU work [{ar}]: CREStereo 1080x1920, 20 iters: cascade {ms:.1f} ms / pair, 2-stage harness {ms2:.1f} ms / pair", flush=True)
+        ms = timeit(lambda: m(f1, f2), 9)
+        best = timeit.best
+        ms2 = timeit(lambda: two_stage_forward(m, f1, f2), 9)
+        print(f"config 5 per-GPU work [{ar}]: CREStereo 1080x1920, 20 iters: cascade {ms:.1f} ms / pair (median of 9; best {best:.1f}), 2-stage harness {ms2:.1f} ms / pair", flush=True)
         del m, f1, f2
         torch.cuda.empty_cache()
         for B in (1, 8):
