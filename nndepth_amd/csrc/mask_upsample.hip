@@ -12,12 +12,30 @@
 //   * the two K-halves are summed into an LDS mask tile [9*R*R][33]; then every thread produces output pixels:
 //     9 logits from LDS -> softmax -> weighted sum of the 3x3 flow neighbourhood -> R*8 contiguous floats per
 //     (tile row, sub-row) so the HBM stores are whole 256-B runs.
+// SPLIT = true (arithmetic 3, round 2): the same GEMM with both operands as 3 bf16 pieces and 6 products per fp32 product on
+// v_mfma_f32_32x32x16_bf16 (conv_split.hip's arithmetic; weights in its packing).  Phase stamps of the exact kernel at 68x120
+// (scripts/stamps_mu.py): stage 3.8 us, K loop 22 (2.4 GFLOP on the fp32 MFMA = 15.3 us at peak: the kernel is matrix-bound),
+// softmax + store 3.2.  The x tile is staged as [16-ch chunk][piece][k half][pixel][8 bf16], so a B fragment is one
+// conflict-free ds_read_b128 per piece, shared by the wave's 3 output-channel blocks.
 #include "common.h"
 #include "layout.h"
 
 namespace nnd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#ifdef NND_DBG_STAMPS
+// debug build only (scripts/build_ablate.sh): per-workgroup phase timestamps, s_memrealtime at 100 MHz
+__device__ unsigned long long g_mu_stamps[4096 * 8];
+#define NND_MSTAMP(i)                                                                             \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_mu_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define NND_MSTAMP(i)
+#endif
 
 struct MaskUpArgs {
     const float* x;
@@ -41,10 +59,11 @@ struct MaskUpCfg {
     static constexpr int NT = 64 * NWAVES;
     static constexpr int NST = CIN / 32;                 // 32-channel steps over K
     static constexpr int MT_STRIDE = 33;
-    static constexpr int LDS_FLOATS = (CIN * 32 > COUT * MT_STRIDE ? CIN * 32 : COUT * MT_STRIDE) + 128;
+    static constexpr int XS_FLOATS = CIN * 32 * 3 / 2;   // x tile: fp32 (CIN*32 floats) or 3 bf16 pieces (1.5x that)
+    static constexpr int LDS_FLOATS = (XS_FLOATS > COUT * MT_STRIDE ? XS_FLOATS : COUT * MT_STRIDE) + 128;
 };
 
-template <int RATE, int CIN>
+template <int RATE, int CIN, bool SPLIT = false>
 __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kernel(MaskUpArgs a) {
     using Cfg = MaskUpCfg<RATE, CIN>;
     constexpr int COUT = Cfg::COUT, NCB = Cfg::NCB, CBW = Cfg::CBW, G = Cfg::G, NT = Cfg::NT, NST = Cfg::NST;
@@ -53,6 +72,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     constexpr int MTS = Cfg::MT_STRIDE;
     static_assert(CIN % 128 == 0 && NST % 2 == 0, "CIN must be a multiple of 128");
     extern __shared__ float lds[];
+    NND_MSTAMP(0);
     float* xs = lds;                          // [CIN][32]   (K loop)
     float* mt = lds;                          // [COUT][33]  (after the K loop; aliases xs)
     float* fp = lds + Cfg::LDS_FLOATS - 128;  // [fc][6][10] flow patch, zero outside the image
@@ -70,6 +90,46 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     // ---- stage the x tile (all CIN channels) and the flow patch
     {
         const float* src = a.x + b * a.xbs;
+        if constexpr (SPLIT) {
+            // item = (pixel, 4 consecutive channels): one 16-B load (c4) or four 4-B loads, split into 3 x 4 bf16 = three 8-B stores
+            unsigned char* xsb = reinterpret_cast<unsigned char*>(lds);
+            constexpr int NQ4 = (CIN / 4 * 32 + NT - 1) / NT;
+            float4 v4[NQ4];
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) {
+                const int e = tid + i * NT;
+                const int qd = e >> 5, px = e & 31;
+                const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
+                const bool ok = e < CIN / 4 * 32 && y < H && x < W;
+                if (a.x_c4) {
+                    v4[i] = *reinterpret_cast<const float4*>(src + (ok ? (unsigned)(qd * 4 * (int)XP + 4 * (int)pix_off(a.lay, y, x)) : 0u));
+                } else {
+                    const unsigned o = ok ? (unsigned)(qd * 4 * (int)XP + (int)pix_off(a.lay, y, x)) : 0u;
+                    v4[i] = make_float4(src[o], src[ok ? o + (unsigned)XP : 0u], src[ok ? o + 2u * (unsigned)XP : 0u], src[ok ? o + 3u * (unsigned)XP : 0u]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NQ4; ++i) {
+                const int e = tid + i * NT;
+                const int qd = e >> 5, px = e & 31;
+                const bool ok = (ty0 + (px >> 3)) < H && (tx0 + (px & 7)) < W;
+                if (e < CIN / 4 * 32) {
+                    float res[4] = {ok ? v4[i].x : 0.f, ok ? v4[i].y : 0.f, ok ? v4[i].z : 0.f, ok ? v4[i].w : 0.f};
+                    const int chunk = qd >> 2, sub = qd & 3;
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) {  // round-to-nearest of the running residual; the subtractions are exact
+                        bf16x4 pv;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            pv[j] = (__bf16)res[j];
+                            res[j] -= (float)pv[j];
+                        }
+                        *reinterpret_cast<uint2*>(xsb + ((((chunk * 3 + sp) * 2 + (sub >> 1)) * 32 + px) * 16 + (sub & 1) * 8)) =
+                            __builtin_bit_cast(uint2, pv);
+                    }
+                }
+            }
+        } else
         if (a.x_c4) {  // one 16-B load per (pixel, 4 channels)
             constexpr int NQ4 = (CIN / 4 * 32 + NT - 1) / NT;
             float4 v4[NQ4];
@@ -120,6 +180,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
         }
     }
     __syncthreads();
+    NND_MSTAMP(1);
 
     // ---- K loop: units u = (step, cbi); A of unit u+1 is prefetched during unit u, B of step s+1 during step s
     f32x16 acc[CBW];
@@ -127,43 +188,90 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     for (int i = 0; i < CBW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    constexpr int SPW = NST / 2;  // steps per wave
-    const int s0 = kj * SPW;
-    const float4* wq = reinterpret_cast<const float4*>(a.wpk);
-    auto a_base = [&](int cbi) {
-        int cb = g * CBW + cbi;
-        cb = cb < NCB ? cb : NCB - 1;  // padded group member: re-reads a valid block, result discarded
-        return wq + (size_t)cb * (NCHUNK * 16 * 64);
-    };
-    float4 ab[2][4];
-    float bq[2][16];
-    auto load_a = [&](float4* dst, int u) {  // u = local unit index
-        const int s = s0 + u / CBW, cbi = u % CBW;
-        const float4* ws = a_base(cbi) + s * (4 * 64);
+    if constexpr (SPLIT) {
+        // weights in pack_conv_split order: uint4 index (((cb * NCH16 + chunk) * 3 + piece) * 64 + lane), lane = k-half * 32 + (co % 32)
+        constexpr int NCH16 = CIN / 16, CPW = NCH16 / 2;  // 16-channel chunks: all / per wave (its K half)
+        const uint4* wq4 = reinterpret_cast<const uint4*>(a.wpk);
+        const unsigned char* xsb = reinterpret_cast<const unsigned char*>(lds);
+        const int c0k = kj * CPW;
+        auto a_ptr = [&](int cbi, int ch) {
+            int cb = g * CBW + cbi;
+            cb = cb < NCB ? cb : NCB - 1;  // padded group member: re-reads a valid block, result discarded
+            return wq4 + (size_t)((cb * NCH16 + c0k + ch) * 3) * 64 + lane;
+        };
+        // a unit (chunk, block) is only 6 MFMAs = 192 cycles: the weight fragments run AD units ahead through a ring of AD + 1
+        // register sets.  (AD = 1 measured the same 22.4 us: the 255 workgroups pull 864 KB of weight pieces each = 220 MB per
+        // launch through the L2s, ~18 TB/s during the K loop — the stream is throughput-bound, not latency-bound.)
+        constexpr int AD = 3, NA = AD + 1, NUNIT = CPW * CBW;
+        uint4 ab[NA][3], bq[2][3];
+        auto load_a = [&](uint4* dst, int u) {
+            const uint4* w = a_ptr(u % CBW, u / CBW);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = ws[(unsigned)(q * 64 + lane)];
-    };
-    auto load_b = [&](float* dst, int sl) {
-        const float* xb = xs + ((s0 + sl) * 32 + h2) * 32 + l31;
+            for (int sp = 0; sp < 3; ++sp) dst[sp] = w[sp * 64];
+        };
+        auto load_b = [&](uint4* dst, int ch) {
 #pragma unroll
-        for (int pair = 0; pair < 16; ++pair) dst[pair] = xb[pair * 64];
-    };
-    load_a(ab[0], 0);
-    load_b(bq[0], 0);
+            for (int sp = 0; sp < 3; ++sp)
+                dst[sp] = *reinterpret_cast<const uint4*>(xsb + (((((c0k + ch) * 3 + sp) * 2 + h2) * 32 + l31) * 16));
+        };
 #pragma unroll
-    for (int u = 0; u < SPW * CBW; ++u) {
-        const int sl = u / CBW, cbi = u % CBW;
-        if (u + 1 < SPW * CBW) load_a(ab[(u + 1) & 1], u + 1);
-        if (cbi == 0 && sl + 1 < SPW) load_b(bq[(sl + 1) & 1], sl + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < AD && u < NUNIT; ++u) load_a(ab[u], u);
+        load_b(bq[0], 0);
 #pragma unroll
-        for (int pair = 0; pair < 16; ++pair) {
-            const float4 av = ab[u & 1][pair / 4];
-            const float as = (pair % 4 == 0) ? av.x : (pair % 4 == 1) ? av.y : (pair % 4 == 2) ? av.z : av.w;
-            acc[cbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bq[sl & 1][pair], acc[cbi], 0, 0, 0);
+        for (int u = 0; u < NUNIT; ++u) {
+            const int ch = u / CBW, cbi = u % CBW;
+            if (u + AD < NUNIT) load_a(ab[(u + AD) % NA], u + AD);
+            if (cbi == 0 && ch + 1 < CPW) load_b(bq[(ch + 1) & 1], ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // x_i * w_j with i + j descending: the small products first (conv_split.hip)
+#pragma unroll
+            for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+                for (int i = 0; i <= sum; ++i)
+                    acc[cbi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ab[u % NA][sum - i]),
+                                                                     __builtin_bit_cast(bf16x8, bq[ch & 1][i]), acc[cbi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    } else {
+        constexpr int SPW = NST / 2;  // steps per wave
+        const int s0 = kj * SPW;
+        const float4* wq = reinterpret_cast<const float4*>(a.wpk);
+        auto a_base = [&](int cbi) {
+            int cb = g * CBW + cbi;
+            cb = cb < NCB ? cb : NCB - 1;  // padded group member: re-reads a valid block, result discarded
+            return wq + (size_t)cb * (NCHUNK * 16 * 64);
+        };
+        float4 ab[2][4];
+        float bq[2][16];
+        auto load_a = [&](float4* dst, int u) {  // u = local unit index
+            const int s = s0 + u / CBW, cbi = u % CBW;
+            const float4* ws = a_base(cbi) + s * (4 * 64);
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = ws[(unsigned)(q * 64 + lane)];
+        };
+        auto load_b = [&](float* dst, int sl) {
+            const float* xb = xs + ((s0 + sl) * 32 + h2) * 32 + l31;
+    #pragma unroll
+            for (int pair = 0; pair < 16; ++pair) dst[pair] = xb[pair * 64];
+        };
+        load_a(ab[0], 0);
+        load_b(bq[0], 0);
+    #pragma unroll
+        for (int u = 0; u < SPW * CBW; ++u) {
+            const int sl = u / CBW, cbi = u % CBW;
+            if (u + 1 < SPW * CBW) load_a(ab[(u + 1) & 1], u + 1);
+            if (cbi == 0 && sl + 1 < SPW) load_b(bq[(sl + 1) & 1], sl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int pair = 0; pair < 16; ++pair) {
+                const float4 av = ab[u & 1][pair / 4];
+                const float as = (pair % 4 == 0) ? av.x : (pair % 4 == 1) ? av.y : (pair % 4 == 2) ? av.z : av.w;
+                acc[cbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bq[sl & 1][pair], acc[cbi], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+    NND_MSTAMP(2);
     __syncthreads();  // everyone is done reading xs: the mask tile may overwrite it
 
     // ---- sum the two K-halves into the LDS mask tile [COUT][33]
@@ -186,6 +294,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
         __syncthreads();
     }
 
+    NND_MSTAMP(3);
     // ---- softmax over the 9 neighbours + convex combination; item = (tile row rr, sub-row i) x (col c, sub-col j)
     constexpr int ROWLEN = 8 * RATE;          // contiguous output floats per item row
     constexpr int NITEM = 4 * RATE * ROWLEN;  // outputs per tile
@@ -219,12 +328,16 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             if (y < H && x < W) a.out[((long)b * a.fc + f) * HW * RATE * RATE + ((long)y * RATE + i) * OW + (long)x * RATE + j] = o;
         }
     }
+#ifdef NND_DBG_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    NND_MSTAMP(4);
 }
 
-template <int RATE, int CIN>
+template <int RATE, int CIN, bool SPLIT = false>
 static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
     using Cfg = MaskUpCfg<RATE, CIN>;
-    auto kern = mask_upsample_kernel<RATE, CIN>;
+    auto kern = mask_upsample_kernel<RATE, CIN, SPLIT>;
     const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised = false;
@@ -245,7 +358,8 @@ bool mask_upsample_supported(int rate, int cin, int flow_channels) {
 
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
                          int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels, bool x_c4) {
-    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == 128 && L.Cout == 9 * rate * rate, "mask_upsample: layer shape");
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == (L.arith ? 16 : 128) && L.Cout == 9 * rate * rate && (L.arith == 0 || L.arith == 3),
+                "mask_upsample: layer shape / packing");
     NND_REQUIRE(mask_upsample_supported(rate, L.Cin, flow_channels), "mask_upsample: rate %d / Cin %d / %d flow channels not built",
                 rate, L.Cin, flow_channels);
     MaskUpArgs a;
@@ -253,10 +367,22 @@ int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, 
     a.H = H; a.W = W; a.tiles_x = cdiv(W, 8); a.fc = flow_channels;
     a.lay = make_lay(H, W, tiled);
     a.x_c4 = (tiled && x_c4) ? 1 : 0;
+    if (L.arith == 3) {  // split-bf16 arithmetic: weights in pack_conv_split's order
+        if (rate == 8 && L.Cin == 256) return launch_mu<8, 256, true>(a, B, stream);
+        if (rate == 8 && L.Cin == 128) return launch_mu<8, 128, true>(a, B, stream);
+        if (rate == 4 && L.Cin == 256) return launch_mu<4, 256, true>(a, B, stream);
+        return launch_mu<4, 128, true>(a, B, stream);
+    }
     if (rate == 8 && L.Cin == 256) return launch_mu<8, 256>(a, B, stream);
     if (rate == 8 && L.Cin == 128) return launch_mu<8, 128>(a, B, stream);
     if (rate == 4 && L.Cin == 256) return launch_mu<4, 256>(a, B, stream);
     return launch_mu<4, 128>(a, B, stream);
 }
+
+#ifdef NND_DBG_STAMPS
+extern "C" int nnd_debug_read_mu_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mu_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace nnd

@@ -65,8 +65,8 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     NND_REQUIRE(cp > 0 && (fc == 1 || fc == 2) && mc > 0 && mc % 9 == 0, "update_block: bad cor_planes/flow_channels/mask_channels");
     NND_REQUIRE(d->gru_kind == 0 || d->gru_kind == 1, "update_block: gru_kind must be 0 (sep_conv) or 1 (conv_gru)");
     NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3, "update_block: arithmetic must be 0 (fp32 MFMA) or 3 (bf16x3 split)");
-    // arithmetic == 3: every MFMA conv whose shape conv_split.hip builds takes the split-bf16 kernel, except convc1 and mask.2
-    // (their weights are consumed by the fused lookup / upsample kernels in the fp32 packing); NND_SPLIT_MASK (diagnostic)
+    // arithmetic == 3: every MFMA conv whose shape conv_split.hip builds takes the split-bf16 kernel (mask.2 inside the fused
+    // mask + upsample kernel), except convc1 (its weights are consumed by the fused lookup kernels in the fp32 packing) and convf2; NND_SPLIT_MASK (diagnostic)
     // restricts it to a subset, bit = ConvId (e.g. 2 = encoder.convc2 only)
     unsigned split_mask = ~0u;
     if (const char* e = getenv("NND_SPLIT_MASK")) split_mask = (unsigned)strtoul(e, nullptr, 0);
@@ -99,7 +99,7 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->L[C_FHM] = mk(3, 3, hid, 3 * hid, &off, ar(C_FHM));  // flow_head.conv1 (hid) and mask.0 (2*hid): same input h, both ReLU -> one conv
     p->fc2_w = off; off += (int64_t)fc * hid * 9;
     p->fc2_b = off; off += 4;  // keep 16-B alignment of what follows
-    p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off);
+    p->L[C_M2] = mk(1, 1, 2 * hid, mc, &off, ar(C_M2));  // consumed by the fused mask + upsample kernel in the same arithmetic
     p->total = off;
     return NND_OK;
 }

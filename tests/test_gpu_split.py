@@ -195,3 +195,38 @@ def test_igev_regulariser_golden_bf16x3(gold, name, B, H, W):
     err = np.abs(cv.geo_aware_cv[0][:, 0].cpu().numpy() - g[name + "_geo0"]).max()
     print(f"\nregulariser bf16x3 {name}: vs reference {err:.2e}")
     assert err <= 2e-5
+
+
+@pytest.mark.parametrize("fc", [1, 2])
+def test_fused_mask_upsample_bf16x3_matches_unfused(raft_sd, monkeypatch, fc):
+    """bf16x3: mask.2 runs inside the fused mask + softmax + upsample kernel on the bf16 MFMA with split operands
+    (mask_upsample_kernel<.., SPLIT>: x tile split while it is staged, weights in conv_split's packing).  Against the
+    unfused pair of launches (NND_NO_FUSED_UPSAMPLE: conv_split 1x1 -> mask in HBM -> convex_upsample): same arithmetic,
+    another K split, so equal to rounding; 1- and 2-channel flow (RAFT-Stereo / CREStereo), ragged 13x22 map, batch 2."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.ops import UpdateBlockEngine  # noqa: F401
+
+    def run():
+        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=fc, spatial_scale=8, arithmetic="bf16x3")
+        weightgen.fill_module_(ub, "update_block.")
+        ub = ub.to(DEV).eval()
+        eng = ub.sync_engine(DEV)
+        torch.manual_seed(31)
+        B, H, W = 2, 13, 22
+        net, inp = torch.tanh(torch.randn(B, 128, H, W)).to(DEV), torch.relu(torch.randn(B, 64, H, W)).to(DEV)
+        if fc == 1:
+            from nndepth_amd.cost_volume import CorrBlock1D
+            f1, f2 = torch.randn(B, 256, H, W, device=DEV), torch.randn(B, 256, H, W, device=DEV)
+            up, low, _ = eng.refine(CorrBlock1D(f1, f2, 4, 4)._pyr, 4, 4, net, inp, 8, 3)
+        else:
+            f1, f2 = torch.randn(B, 256, H, W, device=DEV), torch.randn(B, 256, H, W, device=DEV)
+            up, low, _ = eng.refine_cre(f1, f2, net, inp, 8, 3)
+        return up.clone(), low.clone()
+
+    a_up, a_low = run()
+    monkeypatch.setenv("NND_NO_FUSED_UPSAMPLE", "1")
+    b_up, b_low = run()
+    assert torch.isfinite(a_up).all() and a_up.abs().max() > 0
+    assert torch.equal(a_low, b_low)  # the recurrence itself does not depend on how the mask head is launched
+    assert (a_up - b_up).abs().max().item() <= 2e-5 * max(1.0, b_up.abs().max().item())
