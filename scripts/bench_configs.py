@@ -36,15 +36,15 @@ def main():
     from nndepth_amd.cre_stereo import CREStereoBase, two_stage_forward
     from nndepth_amd.igev_stereo import CostVolumeFilterNetwork, IGEVStereoBase
     from nndepth_amd.raft_stereo import BaseRAFTStereo
-    for ar in ("fp32", "bf16x3"):
+    ar, which = sys.argv[1], sys.argv[2]
+    if which == "kitti":
         m = BaseRAFTStereo(iters=32, context_dim=64, arithmetic=ar)
         weightgen.fill_module_(m)
         m = m.to(dev).eval()
         f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(2, 8, 384, 1248))
         ms = timeit(lambda: m(f1, f2), 7)
         print(f"config 4 per-GPU work [{ar}]: RAFT-Stereo 8 x 384x1248, 32 iters: {ms:.1f} ms / batch = {8e3 / ms:.1f} pairs/s", flush=True)
-        del m, f1, f2
-        torch.cuda.empty_cache()
+    elif which == "cre":
         m = CREStereoBase(iters=20, arithmetic=ar)
         weightgen.fill_module_(m)
         m = m.to(dev).eval()
@@ -53,19 +53,22 @@ def main():
         best = timeit.best
         ms2 = timeit(lambda: two_stage_forward(m, f1, f2), 9)
         print(f"config 5 per-GPU work [{ar}]: CREStereo 1080x1920, 20 iters: cascade {ms:.1f} ms / pair (median of 9; best {best:.1f}), 2-stage harness {ms2:.1f} ms / pair", flush=True)
-        del m, f1, f2
-        torch.cuda.empty_cache()
-        for B in (1, 8):
-            m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=32, hidden_dim=64, context_dim=64, arithmetic=ar)
-            weightgen.fill_module_(m, "igev.")
-            m = m.to(dev).eval()
-            f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(4, B, 544, 960))
-            ms = timeit(lambda: m(f1, f2), 5, warm=2)
-            print(f"config 3 [{ar}]: IGEV 544x960 batch {B}, 32 iters (tiny backbone): {ms:.1f} ms / batch = {B * 1e3 / ms:.2f} pairs/s; "
-                  f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
-            del m, f1, f2
-            torch.cuda.empty_cache()
+    else:
+        B = int(which[4:])
+        m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=32, hidden_dim=64, context_dim=64, arithmetic=ar)
+        weightgen.fill_module_(m, "igev.")
+        m = m.to(dev).eval()
+        f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(4, B, 544, 960))
+        ms = timeit(lambda: m(f1, f2), 5, warm=2)
+        print(f"config 3 [{ar}]: IGEV 544x960 batch {B}, 32 iters (tiny backbone): {ms:.1f} ms / batch = {B * 1e3 / ms:.2f} pairs/s; "
+              f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2:
+        main()
+    else:  # one process per (arithmetic, configuration): every measurement starts from a fresh allocator and library state
+        import subprocess
+        for ar in ("fp32", "bf16x3"):
+            for which in ("kitti", "cre", "igev1", "igev8"):
+                subprocess.run([sys.executable, os.path.abspath(__file__), ar, which], check=False)
