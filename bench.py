@@ -281,7 +281,7 @@ def sharded_config(args):
         from nndepth_amd.prepost import Padder
         from nndepth_amd.raft_stereo import BaseRAFTStereo
         n_pairs, micro, hw = 64, 8, (375, 1242)
-        model = BaseRAFTStereo(iters=ITERS, context_dim=64)
+        model = BaseRAFTStereo(iters=ITERS, context_dim=64, arithmetic=args.arithmetic)
         weightgen.fill_module_(model)
         model = model.to(dev).eval()
         padder = Padder(hw, divis_by=32)
@@ -294,7 +294,7 @@ def sharded_config(args):
     else:
         from nndepth_amd.cre_stereo import CREStereoBase, two_stage_forward
         n_pairs, micro, hw = 8, 1, (1080, 1920)
-        model = CREStereoBase(iters=20)
+        model = CREStereoBase(iters=20, arithmetic=args.arithmetic)
         weightgen.fill_module_(model)
         model = model.to(dev).eval()
 
@@ -331,8 +331,8 @@ def sharded_config(args):
         print(json.dumps({
             "metric": metric, "value": n_pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "pairs_per_step": n_pairs, "pairs_per_rank": len(mine),
+            "vs_baseline": None, "dtype": DTYPE[args.arithmetic], "data": "synthetic",
+            "config": {"workload": name, "arithmetic": args.arithmetic, "pairs_per_step": n_pairs, "pairs_per_rank": len(mine),
                        "parallelism": f"batch shards x{world} + RCCL all-gather of the disparities"}}))
     if world > 1:
         import torch.distributed as dist
