@@ -89,17 +89,20 @@ def test_igev_config3_136x240_vs_oracle(R, B):
     assert torch.equal(got_lk, R.igev_lookup(fp, gp, coords, G, 4, 4))
     del got_lk
     # loop: 2 iterations from the oracle's initial disparity (isolates the loop from the init error above)
-    ub = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4)
-    ub.load_state_dict({k[len("update_block."):]: v for k, v in ub_sd.items()})
-    eng = ub.to(DEV).sync_engine(DEV)
-    args = (cv._feat, cv._geo, G, 4, 4, net.to(DEV), inp.to(DEV), 4, iters)
-    up, low, _ = eng.refine_igev(*args, disp_init=init.to(DEV))
-    up_il, low_il, _ = eng.refine_igev(*args, disp_init=init.to(DEV), interleaved=cv.interleaved())
-    errs = [(up[i].cpu() - exp[i]).abs().max().item() for i in range(iters)]
-    scale = max(1.0, exp[-1].abs().max().item() / 40)
-    print(f"[config3 B={B}] loop max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs), f"(|coords| max {exp[-1].abs().max().item():.0f})")
-    assert max(errs) <= 2e-4 * scale
-    assert torch.equal(up_il, up) and torch.equal(low_il, low)  # interleaved gather == reference-layout gather, bit for bit
+    # (both arithmetics: 32 640 pixels = 510 workgroup columns, the split kernel's large-map workgroup shapes)
+    for ar in ("fp32", "bf16x3"):
+        ub = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4, arithmetic=ar)
+        ub.load_state_dict({k[len("update_block."):]: v for k, v in ub_sd.items()})
+        eng = ub.to(DEV).sync_engine(DEV)
+        args = (cv._feat, cv._geo, G, 4, 4, net.to(DEV), inp.to(DEV), 4, iters)
+        up, low, _ = eng.refine_igev(*args, disp_init=init.to(DEV))
+        up_il, low_il, _ = eng.refine_igev(*args, disp_init=init.to(DEV), interleaved=cv.interleaved())
+        errs = [(up[i].cpu() - exp[i]).abs().max().item() for i in range(iters)]
+        scale = max(1.0, exp[-1].abs().max().item() / 40)
+        print(f"[config3 B={B} {ar}] loop max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs),
+              f"(|coords| max {exp[-1].abs().max().item():.0f})")
+        assert max(errs) <= 2e-4 * scale
+        assert torch.equal(up_il, up) and torch.equal(low_il, low)  # interleaved gather == reference-layout gather, bit for bit
 
 
 # ------------------------------------------------------------------------------------------ config 4: KITTI batch 8
@@ -111,24 +114,25 @@ def test_raft_config4_kitti_batch8_vs_oracle(raft_sd, R):
     from nndepth_amd.raft_stereo import BaseRAFTStereo
     iters, Bn = 4, 8
     f1, f2 = weightgen.synthetic_frames(11, Bn, 375, 1242)
-    m = BaseRAFTStereo(iters=iters, context_dim=64)
-    m.load_state_dict(raft_sd, strict=True)
-    m = m.to(DEV).eval()
-    padder = Padder((375, 1242), divis_by=32)
-    p1, p2 = padder.pad(f1.to(DEV), f2.to(DEV))
-    assert tuple(p1.shape) == (Bn, 3, 384, 1248)
-    out = m(p1, p2)
-    got = [padder.unpad(o["up_disp"]).cpu() for o in out]
-    assert tuple(got[-1].shape) == (Bn, 1, 375, 1242)
     pads = R.padder_pads((375, 1242), 32)
     with torch.no_grad():
         ref = R.raft_stereo_forward(raft_sd, R.padder_pad(f1, pads), R.padder_pad(f2, pads), iters)
-    errs = [(g - R.padder_unpad(r, pads)).abs().max().item() for g, r in zip(got, ref)]
-    print(f"\n[config4] 8 x 375x1242, {iters} iterations, max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
-    assert max(errs) <= 1e-4
-    # per-sample independence at this size: sample 5 alone gives the same bits as inside the batch
-    one = m(p1[5:6].contiguous(), p2[5:6].contiguous())[-1]["up_disp"]
-    assert (one[0] - out[-1]["up_disp"][5]).abs().max().item() <= 2e-5
+    padder = Padder((375, 1242), divis_by=32)
+    p1, p2 = padder.pad(f1.to(DEV), f2.to(DEV))
+    assert tuple(p1.shape) == (Bn, 3, 384, 1248)
+    for ar in ("fp32", "bf16x3"):  # batch 8 = 960 workgroup columns: the split kernel's large-map workgroup shapes
+        m = BaseRAFTStereo(iters=iters, context_dim=64, arithmetic=ar)
+        m.load_state_dict(raft_sd, strict=True)
+        m = m.to(DEV).eval()
+        out = m(p1, p2)
+        got = [padder.unpad(o["up_disp"]).cpu() for o in out]
+        assert tuple(got[-1].shape) == (Bn, 1, 375, 1242)
+        errs = [(g - R.padder_unpad(r, pads)).abs().max().item() for g, r in zip(got, ref)]
+        print(f"\n[config4 {ar}] 8 x 375x1242, {iters} iterations, max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
+        assert max(errs) <= 1e-4
+        # per-sample independence at this size: sample 5 alone (another workgroup shape) agrees with sample 5 of the batch
+        one = m(p1[5:6].contiguous(), p2[5:6].contiguous())[-1]["up_disp"]
+        assert (one[0] - out[-1]["up_disp"][5]).abs().max().item() <= 2e-5
 
 
 # ------------------------------------------------------------------------------------------ config 5: CREStereo 1080x1920
@@ -139,13 +143,14 @@ def test_cre_config5_1080x1920_vs_oracle(cre_sd):
     from nndepth_amd import weightgen
     from nndepth_amd.cre_stereo import CREStereoBase
     fr1, fr2 = weightgen.synthetic_frames(13, 1, 1080, 1920)
-    m = CREStereoBase(iters=2)
-    m.load_state_dict(cre_sd, strict=True)
-    m = m.to(DEV).eval()
-    outs = m(fr1.to(DEV), fr2.to(DEV))
     with torch.no_grad():
         exp = CR.cre_stereo_forward(cre_sd, fr1, fr2, 2)
-    assert len(outs) == len(exp) == 4 and tuple(outs[-1]["up_disp"].shape) == (1, 2, 1080, 1920)
-    errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
-    print("\n[config5] 1080x1920 it2 max-abs per output:", " ".join(f"{e:.1e}" for e in errs), f"(|flow| max {exp[-1].abs().max():.1f})")
-    assert max(errs) <= 1e-4
+    for ar in ("fp32", "bf16x3"):
+        m = CREStereoBase(iters=2, arithmetic=ar)
+        m.load_state_dict(cre_sd, strict=True)
+        m = m.to(DEV).eval()
+        outs = m(fr1.to(DEV), fr2.to(DEV))
+        assert len(outs) == len(exp) == 4 and tuple(outs[-1]["up_disp"].shape) == (1, 2, 1080, 1920)
+        errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
+        print(f"\n[config5 {ar}] 1080x1920 it2 max-abs per output:", " ".join(f"{e:.1e}" for e in errs), f"(|flow| max {exp[-1].abs().max():.1f})")
+        assert max(errs) <= 1e-4
