@@ -20,7 +20,8 @@
  *     (rounds 1-2 ran one branch of the loop on an internal side stream; measured equal, removed);
  *   - diagnostic environment switches (read per call; they select between kernels that the parity tests prove
  *     equivalent, never a non-HIP path): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
- *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
+ *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_FUSED_FLOW_BRANCH (convf1 and convf2 as two launches when
+ *     arithmetic = 3), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
  *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_AGCL_V1 (one-pixel-per-lane AGCL kernels), NND_AGCL_PB (pixels per workgroup of the channels-last offset kernel), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC

@@ -108,6 +108,11 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
 // launch_conv / pack_conv dispatch to these.
 bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith);
 int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W, hipStream_t stream);
+// motion encoder flow branch in one launch (conv_split.hip): f2 = convf2's split-packed layer, w7t = convf1's weights tap-major
+// ([fc*49][128]), b7 its bias
+bool flow_branch_supported(const ConvLayer& f2, int fc);
+int launch_flow_branch(const ConvLayer& f2, const float* blob, const float* w7t, const float* b7, const float* flow, int64_t fbs,
+                       int fc, const ConvIO& io, int B, int H, int W, hipStream_t stream);
 void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, const float* const* b, const int* cout, float* blob,
                      const int* ci_map, int cin_src);
 

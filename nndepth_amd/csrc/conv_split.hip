@@ -612,7 +612,242 @@ void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Flow branch of the motion encoder as ONE launch (arithmetic 3):  out = relu(conv3x3_{128->64}(relu(conv7x7_{FC->128}(flow))))
+//   nndepth/blocks/update_block.py:26-36, 57-65 (BasicMotionEncoder.convf1 / convf2)
+// The two launches it replaces cost 9.8 + 21.4 us of a 322-us iteration for 1.3 GFLOP.  One workgroup = one 4x8 sub-tile, 8 waves:
+//   phase 0  the 12x16 flow window of the sub-tile, the 7x7 weights (tap-major copy made at pack time: 4 consecutive channels
+//            = one 16-B read) and their bias into LDS;
+//   phase 1  f1 on the 6x10 halo patch: a thread = 2 horizontally adjacent positions x 8 channels (one 16-B slot of the patch) —
+//            a window row in registers, each 16-B weight read feeds 8 FMAs (the first attempt at this fusion, inside the generic
+//            kernel's staging units, did one LDS read per FMA and took 51 us) — per channel in convf1_kernel's tap order;
+//            bias, ReLU, zero outside the image (convf2's padding), split into 3 bf16 pieces, written in conv_split's patch
+//            layout (so the 128-channel map never exists in HBM);
+//   phase 2  conv_split's MFMA walk: wave = (output block, K slice of 4), slice kj takes chunks kj and kj + 4; 6 products per
+//            step, small ones first; with 2 waves per SIMD nothing else hides the L2 latency of the weight fragments, so they run
+//            FB_AD steps ahead through a register ring (one step ahead: 35.8 us for the launch);
+//   phase 3  the four K slices meet in LDS (slice 0 + 1 + 2 + 3), shared epilogue (bias, ReLU, c4 or planar store).
+// Arithmetic and summation order are those of convf1_kernel followed by conv_split with ks = 4: bit-identical to that pair
+// (tests/test_gpu_split.py).
 #ifdef NND_DBG_STAMPS
+__device__ unsigned long long g_fb_stamps[4096 * 8];
+#define NND_FSTAMP(i)                                                                                        \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_fb_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define NND_FSTAMP(i)
+#endif
+
+struct FlowBranchArgs {
+    const float* flow;  // (B, FC, H, W) planar tile-major
+    long fbs;
+    const float* w7t;   // [FC*49][128]: convf1's weights tap-major (transposed at pack time)
+    const float* b7;    // [128]
+    ConvArgs c;         // convf2: wpk (pack_conv_split order), bias, out0 / obs0, ld, H, W, Cout = 64, epi = EPI_RELU, tiles_x, npos
+    Lay lf;             // layout of `flow`
+};
+
+constexpr int FB_C1 = 128, FB_NCH = FB_C1 / 16, FB_PR = 6, FB_PC = 10, FB_WR = FB_PR + 6, FB_WC = FB_PC + 6;
+__host__ __device__ constexpr int fb_rowb() { return split_row_bytes(FB_PC, 3); }
+__host__ __device__ constexpr int fb_subb() { return FB_PR * fb_rowb(); }
+template <int FC>
+__host__ __device__ constexpr int fb_lds_bytes() {
+    return 4 * (FC * FB_WR * FB_WC + FC * 49 * FB_C1 + FB_C1) + FB_NCH * fb_subb() + 2 * 3 * 1024 * 4;
+}
+
+template <int FC>
+__global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
+    constexpr int PS = split_pos_bytes(3), ROWB = fb_rowb(), SUBB = fb_subb();
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* win = reinterpret_cast<float*>(lds_raw);                 // [FC][12][16]
+    float* w7l = win + FC * FB_WR * FB_WC;                          // [FC*49][128]
+    float* b7l = w7l + FC * 49 * FB_C1;                             // [128]
+    unsigned char* patch = reinterpret_cast<unsigned char*>(b7l + FB_C1);  // [8 chunks][6][ROWB]
+    float* red = reinterpret_cast<float*>(patch + FB_NCH * SUBB);   // [3 slices][2 blocks][16 regs][64 lanes]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int H = a.c.H, W = a.c.W;
+    const int ty0 = ((int)blockIdx.x / a.c.tiles_x) * 4, tx0 = ((int)blockIdx.x % a.c.tiles_x) * 8;
+    const long FP = a.lf.plane;
+    NND_FSTAMP(0);
+
+    // wave = (output block, K slice) of phase 2 — conv_split's wave = kj * wco + cbi with wco = 2, ks = 4.  Its first FB_AD weight
+    // fragments are requested NOW: they depend on nothing and arrive while phases 0 and 1 run.
+    const int cbi = wave & 1, kj = wave >> 1;
+    const uint4* wq = reinterpret_cast<const uint4*>(a.c.wpk) + (size_t)cbi * FB_NCH * (9 * 3 * 64) + lane;
+    constexpr int NSTEP = (FB_NCH / 4) * 9;  // (chunk, tap) steps of a K slice
+    constexpr int FB_AD = 5, NA = FB_AD + 1;
+    uint4 ab[NA][3];
+    auto load_a = [&](uint4 (&dst)[3], int st) {
+        const int ch = 4 * (st / 9) + kj, t = st % 9;
+        const uint4* w = wq + (size_t)(ch * 9 + t) * (3 * 64);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) dst[sp] = w[sp * 64];
+    };
+#pragma unroll
+    for (int st = 0; st < FB_AD; ++st) load_a(ab[st], st);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- phase 0
+    for (int e = tid; e < FC * FB_WR * FB_WC; e += 512) {
+        const int cch = e / (FB_WR * FB_WC), rr = (e / FB_WC) % FB_WR, cc = e % FB_WC;
+        const int gy = ty0 + rr - 4, gx = tx0 + cc - 4;  // window row rr = patch row rr - 3 = image row ty0 - 1 + (rr - 3)
+        win[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? a.flow[b * a.fbs + cch * FP + pix_off(a.lf, gy, gx)] : 0.f;
+    }
+    for (int e = tid; e < FC * 49 * FB_C1 / 4; e += 512)
+        reinterpret_cast<float4*>(w7l)[e] = reinterpret_cast<const float4*>(a.w7t)[e];
+    if (tid < FB_C1) b7l[tid] = a.b7[tid];
+    __syncthreads();
+    NND_FSTAMP(1);
+
+    // ---- phase 1
+    {
+        const int pp = tid & 31, gh = tid >> 5;  // position pair (30 of them), (16-channel chunk, 8-channel half): all 8 waves
+        const int g = gh >> 1, h = gh & 1;
+        if (pp < 30) {
+            const int pr = pp / 5, pc0 = (pp % 5) * 2;
+            float acc[2][8];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
+#pragma unroll 1
+            for (int cch = 0; cch < FC; ++cch)
+#pragma unroll 1
+                for (int dy = 0; dy < 7; ++dy) {  // rolled: one window row (8 values) and one tap's 8 weights live at a time
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {  // pc0 is even: 8-byte aligned pairs
+                        const float2 t2 = *reinterpret_cast<const float2*>(win + (cch * FB_WR + pr + dy) * FB_WC + pc0 + 2 * q);
+                        v[2 * q] = t2.x; v[2 * q + 1] = t2.y;
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 7; ++dx) {
+                        const float4* wt = reinterpret_cast<const float4*>(w7l + ((cch * 49 + dy * 7 + dx) * FB_C1 + g * 16 + h * 8));
+                        const float4 w0 = wt[0], w1 = wt[1];
+                        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wv[j], v[dx + p], acc[p][j]);
+                    }
+                }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int pc = pc0 + p;
+                const int gy = ty0 + pr - 1, gx = tx0 + pc - 1;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                float val[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[j] = in ? fmaxf(acc[p][j] + b7l[g * 16 + 8 * h + j], 0.f) : 0.f;
+                uint4 pieces[3];
+                split_pieces<3>(val, pieces);
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    *reinterpret_cast<uint4*>(patch + g * SUBB + pr * ROWB + pc * PS + sp * 32 + h * 16) = pieces[sp];
+            }
+        }
+    }
+    __syncthreads();
+    NND_FSTAMP(2);
+
+    // ---- phase 2
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int pxl = lane_pixel(l31), r = pxl >> 3, c = pxl & 7;
+    f32x16 acc[1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
+    const unsigned char* xb = patch + r * ROWB + c * PS + h2 * 16;
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int ch = 4 * (st / 9) + kj, t = st % 9;
+        if (st + FB_AD < NSTEP) load_a(ab[(st + FB_AD) % NA], st + FB_AD);
+        uint4 bq[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) bq[sp] = *reinterpret_cast<const uint4*>(xb + ch * SUBB + (t / 3) * ROWB + (t % 3) * PS + sp * 32);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch where it is: the scheduler otherwise sinks every load to its use
+#pragma unroll
+        for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+            for (int i = 0; i <= sum; ++i)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ab[st % NA][sum - i]),
+                                                                __builtin_bit_cast(bf16x8, bq[i]), acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    NND_FSTAMP(3);
+    // ---- phase 3
+    if (kj > 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[(((kj - 1) * 2 + cbi) * 16 + reg) * 64 + lane] = acc[0][reg];
+    }
+    __syncthreads();
+    if (kj > 0) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float sum = acc[0][reg];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) sum += red[((sl * 2 + cbi) * 16 + reg) * 64 + lane];
+        acc[0][reg] = sum;
+    }
+    const int ys[1] = {ty0 + r}, xs[1] = {tx0 + c};
+    conv_epilogue<1>(a.c, acc, cbi, b, h2, 0, 16, ys, xs);
+#ifdef NND_DBG_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    NND_FSTAMP(4);
+}
+
+bool flow_branch_supported(const ConvLayer& f2, int fc) {
+    return f2.arith == 3 && f2.KH == 3 && f2.KW == 3 && f2.Cin == FB_C1 && f2.Cout == 64 && f2.stride == 1 && (fc == 1 || fc == 2);
+}
+
+int launch_flow_branch(const ConvLayer& f2, const float* blob, const float* w7t, const float* b7, const float* flow, int64_t fbs,
+                       int fc, const ConvIO& io, int B, int H, int W, hipStream_t stream) {
+    NND_REQUIRE(flow_branch_supported(f2, fc), "flow_branch: built for convf1 7x7 (1 or 2 -> 128) + convf2 3x3 (128 -> 64) in split arithmetic");
+    NND_REQUIRE(io.dst_tiled && f2.CI_T == 16 && f2.nchunks == FB_NCH, "flow_branch: tile-major destination, 16-channel chunks");
+    NND_REQUIRE((long)(fc + 64) * tiled_plane(H, W) < (1L << 31), "flow_branch: plane offsets exceed 32 bits");
+    FlowBranchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.flow = flow; a.fbs = (long)fbs; a.w7t = w7t; a.b7 = b7;
+    a.lf = make_lay(H, W, true);
+    a.c.wpk = blob + f2.w_off;
+    a.c.bias = blob + f2.b_off;
+    a.c.out0 = io.out0.ptr; a.c.obs0 = io.out0.bstride;
+    a.c.ld = make_lay(H, W, true, io.dst_c4);
+    a.c.H = H; a.c.W = W; a.c.Hin = H; a.c.Win = W; a.c.Cout = f2.Cout; a.c.epi = EPI_RELU;
+    a.c.tiles_x = cdiv(W, 8);
+    a.c.npos = a.c.tiles_x * cdiv(H, 4);
+    a.c.scale = 1.f;
+    dim3 grid(a.c.npos, 1, B), block(512);
+    if (fc == 1) {
+        auto kern = flow_branch_kernel<1>;
+        static bool raised = false;
+        if (!raised) {
+            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, fb_lds_bytes<1>(), stream, a);
+    } else {
+        auto kern = flow_branch_kernel<2>;
+        static bool raised = false;
+        if (!raised) {
+            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, fb_lds_bytes<2>(), stream, a);
+    }
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+#ifdef NND_DBG_STAMPS
+extern "C" int nnd_debug_read_fb_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fb_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
 extern "C" int nnd_debug_read_split_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }

@@ -37,6 +37,7 @@ struct Plan {
     bool sep;
     ConvLayer L[C_COUNT];
     int64_t f1_w, f1_b;  // raw encoder.convf1 weights [128][fc][49] + bias [128]
+    int64_t f1_wt;       // the same weights tap-major [fc*49][128] for the fused flow-branch kernel
     int64_t fc2_w, fc2_b;  // raw flow_head.conv2 weights [fc][hid][9] + bias [fc] (VALU kernel)
     int64_t total;
 };
@@ -79,7 +80,8 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->L[C_C2] = mk(3, 3, 256, 192, &off, ar(C_C2));
     p->f1_w = off; off += (int64_t)128 * fc * 49;
     p->f1_b = off; off += 128;
-    p->L[C_F2] = mk(3, 3, 128, 64, &off);  // exact kernel: 19.7 us there, 19.6 us on the split kernel (K = 8 chunks, Cout 64: all fixed cost)
+    p->f1_wt = off; off += (int64_t)128 * fc * 49;
+    p->L[C_F2] = mk(3, 3, 128, 64, &off, ar(C_F2));  // split arithmetic: ONE launch with convf1 (run_flow_branch)
     p->L[C_CV] = mk(3, 3, 256, hid - fc, &off, ar(C_CV));
     for (int pass = 0; pass < (p->sep ? 2 : 1); ++pass) {
         const int kh = p->sep ? (pass == 0 ? 1 : 5) : 3, kw = p->sep ? (pass == 0 ? 5 : 1) : 3;
@@ -477,6 +479,24 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     return debug_sync("flow_head.conv2", s);
 }
 
+// Flow branch of the motion encoder: convf1 (7x7 on the flow) -> convf2 (3x3) -> cf[192:256].  Split arithmetic: one launch
+// (conv_split.hip: flow_branch_kernel), the 128-channel intermediate never reaches HBM; exact arithmetic, or
+// NND_NO_FUSED_FLOW_BRANCH (which the parity test toggles): convf1_kernel into w.f1, then the conv.
+static int run_flow_branch(const Plan& p, const float* blob, const Bufs& w, const float* flow, Act corr, int B, int H, int W,
+                           hipStream_t s) {
+    const int fc = p.d.flow_channels;
+    const int64_t n = tiled_plane(H, W);
+    if (flow_branch_supported(p.L[C_F2], fc) && !getenv("NND_NO_FUSED_FLOW_BRANCH")) {
+        const ConvIO io = conv_io(p, w, C_F2, corr, n, nullptr, nullptr);
+        int rc = launch_flow_branch(p.L[C_F2], blob, blob + p.f1_wt, blob + p.f1_b, flow, (int64_t)fc * n, fc, io, B, H, W, s);
+        if (rc != NND_OK) return rc;
+        return debug_sync("encoder.convf1+convf2", s);
+    }
+    int rc = run_convf1(p, blob, flow, (int64_t)fc * n, w.f1, B, H, W, s);
+    if (rc != NND_OK) return rc;
+    return run_conv(p, blob, w, C_F2, corr, nullptr, nullptr, B, H, W, s);
+}
+
 // One application of the update block on workspace state: expects h/inp/flow already in w.hx,
 // `flow` = (B,fc,H,W) dense.  Writes new h into w.hx[0:hid], delta, and (optionally) the mask.  Single stream.
 static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr, const float* flow, float* mask_dst,
@@ -488,8 +508,7 @@ static int run_update(const Plan& p, const float* blob, const Bufs& w, Act corr,
     } while (0)
     NND_TRY(run_conv(p, blob, w, C_C1, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_C2, corr, nullptr, nullptr, B, H, W, s));
-    NND_TRY(run_convf1(p, blob, flow, (int64_t)p.d.flow_channels * tiled_plane(H, W), w.f1, B, H, W, s));
-    NND_TRY(run_conv(p, blob, w, C_F2, corr, nullptr, nullptr, B, H, W, s));
+    NND_TRY(run_flow_branch(p, blob, w, flow, corr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_CV, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_ZR1, corr, nullptr, nullptr, B, H, W, s));
     NND_TRY(run_conv(p, blob, w, C_Q1, corr, nullptr, nullptr, B, H, W, s));
@@ -564,6 +583,8 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
     one(C_C2, 2);
     memcpy(out + p.f1_w, t[4], sizeof(float) * 128 * fc * 49);
     memcpy(out + p.f1_b, t[5], sizeof(float) * 128);
+    for (int ch = 0; ch < 128; ++ch)
+        for (int k = 0; k < fc * 49; ++k) out[p.f1_wt + (int64_t)k * 128 + ch] = t[4][(int64_t)ch * fc * 49 + k];
     one(C_F2, 6);
     one(C_CV, 8);
     // GRU convs three ways: full (API path), [h | motion+flow] channels only (loop), `inp` channels only
@@ -736,7 +757,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     for (int id : {(int)C_ZR1C, (int)C_Q1C, (int)C_ZR2C, (int)C_Q2C})
         if (p.sep || id < C_ZR2C) NND_TRY(run_conv(p, packed, w, id, c, nullptr, nullptr, B, H, W, s));
     // Per-iteration schedule, all on the caller's stream:
-    //   convf1, convf2 (flow branch of the motion encoder), lookup (+convc1), convc2, conv, zr1, q1, zr2, q2,
+    //   convf1 + convf2 (flow branch of the motion encoder: one launch in split arithmetic), lookup (+convc1), convc2, conv, zr1, q1, zr2, q2,
     //   flow_head.conv1+mask.0, flow_head.conv2+advance, mask.2 + convex upsample (fused)
     // Rounds 1-2 ran the flow branch on a low-priority side stream beside lookup / convc2 (per-call fork/join events).
     // Measured on MI355X, same box, ms per 544x960 pair: side stream 11.79, in line 11.82 (KITTI batch 8 70.5 / 71.0,
@@ -758,8 +779,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         return rc_;
     };
     for (int it = 0; it < iters; ++it) {
-        NND_TRY(run_convf1(p, packed, w.flow, (int64_t)fc * n, w.f1, B, H, W, s));
-        NND_TRY(loop_conv(C_F2));
+        probe_mark(C_F2, s);
+        NND_TRY(run_flow_branch(p, packed, w, w.flow, c, B, H, W, s));
+        probe_mark(C_F2, s);
         if (fused_lk && interleaved && igev_lookup_convc1_il_supported(groups, num_levels, radius)) {  // IGEV over the group-interleaved copy of both pyramids
             NND_TRY(igev_lookup_convc1_il_launch(interleaved, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W, num_levels,
                                                  radius, s, ws_c4()));

@@ -230,3 +230,34 @@ def test_fused_mask_upsample_bf16x3_matches_unfused(raft_sd, monkeypatch, fc):
     assert torch.isfinite(a_up).all() and a_up.abs().max() > 0
     assert torch.equal(a_low, b_low)  # the recurrence itself does not depend on how the mask head is launched
     assert (a_up - b_up).abs().max().item() <= 2e-5 * max(1.0, b_up.abs().max().item())
+
+
+@pytest.mark.parametrize("fc", [1, 2])
+def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc):
+    """bf16x3: the motion encoder's flow branch is ONE launch (conv_split.hip: flow_branch_kernel) — convf1's 7x7 on the VALU
+    from an LDS copy of the flow window in convf1_kernel's tap order, its output split into bf16 pieces straight into convf2's
+    LDS patch, then conv_split's MFMA walk with 4 K slices.  With every conv forced to ks = 4
+    (NND_SPLIT_CFG), the two-launch path (NND_NO_FUSED_FLOW_BRANCH) computes the same sums in the same order: every output of
+    the update block must match bit for bit.  Ragged 13x22 map (cut sub-tiles on both axes), batch 2, a flow far larger
+    than the map so that every border tap of the 7x7 and of the 3x3 is exercised."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+
+    def run():
+        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=fc, spatial_scale=8, arithmetic="bf16x3")
+        weightgen.fill_module_(ub, "update_block.")
+        ub = ub.to(DEV).eval()
+        torch.manual_seed(21)
+        net, inp = torch.tanh(torch.randn(2, 128, 13, 22)), torch.relu(torch.randn(2, 64, 13, 22))
+        corr, flow = torch.randn(2, 36, 13, 22), torch.randn(2, fc, 13, 22) * 30
+        with torch.no_grad():
+            return [o.clone() for o in ub(net.to(DEV), inp.to(DEV), corr.to(DEV), flow.to(DEV))]
+
+    monkeypatch.setenv("NND_SPLIT_CFG", "0,4")  # ks = 4 for every conv of both runs (ny is free: it does not change any sum)
+    a = run()
+    monkeypatch.setenv("NND_NO_FUSED_FLOW_BRANCH", "1")
+    b = run()
+    assert len(a) == len(b) == 3
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.isfinite(x).all()
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
