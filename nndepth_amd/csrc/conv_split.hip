@@ -761,6 +761,12 @@ __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
     const unsigned char* xb = patch + r * ROWB + c * PS + h2 * 16;
+    // convf2's bias for this lane's 16 output channels, requested before the walk (the shared epilogue would fetch it after the
+    // K-slice sum, on the kernel's critical tail)
+    float bias_r[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) bias_r[reg] = a.c.bias[cbi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int ch = 4 * (st / 9) + kj, t = st % 9;
@@ -793,8 +799,30 @@ __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
         for (int sl = 0; sl < 3; ++sl) sum += red[((sl * 2 + cbi) * 16 + reg) * 64 + lane];
         acc[0][reg] = sum;
     }
-    const int ys[1] = {ty0 + r}, xs[1] = {tx0 + c};
-    conv_epilogue<1>(a.c, acc, cbi, b, h2, 0, 16, ys, xs);
+    // epilogue: relu(sum + bias), the arithmetic of conv_epilogue's EPI_RELU; 16-B stores in the c4 layout
+    const int y = ty0 + r, x = tx0 + c;
+    if (y < H && x < W) {
+        const long DP = a.c.ld.plane, pix = pix_off(a.c.ld, y, x);
+        float* o = a.c.out0 + b * a.c.obs0 + pix;
+        if (a.c.ld.ci == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co0 = cbi * 32 + 8 * q + 4 * h2;
+                float4 v4;
+                v4.x = fmaxf(acc[0][4 * q] + bias_r[4 * q], 0.f);
+                v4.y = fmaxf(acc[0][4 * q + 1] + bias_r[4 * q + 1], 0.f);
+                v4.z = fmaxf(acc[0][4 * q + 2] + bias_r[4 * q + 2], 0.f);
+                v4.w = fmaxf(acc[0][4 * q + 3] + bias_r[4 * q + 3], 0.f);
+                *reinterpret_cast<float4*>(o + (long)co0 * DP) = v4;
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = cbi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+                o[(long)co * DP] = fmaxf(acc[0][reg] + bias_r[reg], 0.f);
+            }
+        }
+    }
 #ifdef NND_DBG_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
 #endif
