@@ -189,6 +189,8 @@ def main():
                 continue  # fused into lookup+convc1 / into mask+upsample: no launch of their own in the loop
             r["ms_in_loop"] = eng.profile_loop_conv(i, pyr, 4, 4, net, inp, 8, ITERS)
             r["tflops_in_loop"] = r["gflop"] / r["ms_in_loop"]
+            if r["conv"] == "encoder.convf2":  # the probe brackets the whole flow branch: convf1 + convf2 (one launch with bf16x3)
+                r["in_loop_covers"] = "encoder.convf1 + encoder.convf2"
             loop_ms += r["ms_in_loop"]
             loop_fl += r["gflop"]
         nprod = SPLIT_PRODUCTS[args.arithmetic]  # MFMA FLOPs executed per algorithmic FLOP
