@@ -427,23 +427,29 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
 
 // relu(acc + bias) of one lane's pixel and 16 channels into c1: planar tile-major, or (out_c4) the 4-channel-interleaved
 // tile-major layout of layout.h, where registers 4q..4q+3 are one 16-B store
+// the lane's 16 bias values (accumulator register order), loaded by the callers BEFORE their MFMA loops: fetched inside the
+// store they sat on the kernel's critical tail (the flow-branch kernel lost 5 us that way)
+__device__ __forceinline__ void load_c1_bias(const float* __restrict__ bias, int cb, int h2, float (&br)[16]) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) br[reg] = bias[cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2];
+}
 __device__ __forceinline__ void store_c1(float* __restrict__ out_b, const Lay& lay, int y, int x, int cb, int h2, const f32x16& acc,
-                                         const float* __restrict__ bias, int out_c4) {
+                                         const float (&br)[16], int out_c4) {
     const long po = pix_off(lay, y, x);  // lay: the planar tile-major layout of coords (ci = 1)
     if (out_c4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int co0 = cb * 32 + 8 * q + 4 * h2;
             *reinterpret_cast<float4*>(out_b + (long)co0 * lay.plane + po * 4) =
-                make_float4(fmaxf(acc[4 * q] + bias[co0], 0.f), fmaxf(acc[4 * q + 1] + bias[co0 + 1], 0.f),
-                            fmaxf(acc[4 * q + 2] + bias[co0 + 2], 0.f), fmaxf(acc[4 * q + 3] + bias[co0 + 3], 0.f));
+                make_float4(fmaxf(acc[4 * q] + br[4 * q], 0.f), fmaxf(acc[4 * q + 1] + br[4 * q + 1], 0.f),
+                            fmaxf(acc[4 * q + 2] + br[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3] + br[4 * q + 3], 0.f));
         }
     } else {
         float* o = out_b + po;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-            o[(long)co * lay.plane] = fmaxf(acc[reg] + bias[co], 0.f);
+            o[(long)co * lay.plane] = fmaxf(acc[reg] + br[reg], 0.f);
         }
     }
 }
@@ -508,33 +514,49 @@ __global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restr
         for (int j = 0; j < 2; ++j)
             xs[buf][(cs + 16 * j) * 32 + px] = cf[j] == 2.0f ? 0.f : cf[j] * v0[j] + (1.0f - cf[j]) * v1[j];
     };
+    // what does not depend on the coordinates is requested first: this wave's bias and the weight fragments of chunk 0 (the packed
+    // layer's K is padded to whole 32-channel chunks, so all 4 fragments of a chunk exist)
+    const int cb = wave;  // 8 waves = 256 output channels
+    // cb_stride: float4s per output-channel block of the packed layer (its K is padded to whole CI_T chunks)
+    const float4* wb = reinterpret_cast<const float4*>(wpk) + (size_t)cb * cb_stride;
+    float br[16];
+    load_c1_bias(bias, cb, h2, br);
+    float4 aw[4], an[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aw[q] = wb[q * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
     fetch(0);
     put(0);
     __syncthreads();
-    const int cb = wave;  // 8 waves = 256 output channels
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // cb_stride: float4s per output-channel block of the packed layer (its K is padded to whole CI_T chunks)
-    const float4* wb = reinterpret_cast<const float4*>(wpk) + (size_t)cb * cb_stride;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
-        if (more) fetch(chunk + 1);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) an[q] = wb[(size_t)(chunk + 1) * (4 * 64) + q * 64 + lane];
+            fetch(chunk + 1);
+        }
         const int npair = min(16, (nch - chunk * 32 + 1) / 2);  // k-pairs that hold real channels
         const float* xb = xs[chunk & 1] + h2 * 32 + l31;
-        for (int q = 0; q * 4 < npair; ++q) {
-            const float4 av = wb[(size_t)chunk * (4 * 64) + q * 64 + lane];
-            const float as[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float as[4] = {aw[q].x, aw[q].y, aw[q].z, aw[q].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (q * 4 + j < npair) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], xb[(q * 4 + j) * 64], acc, 0, 0, 0);
         }
-        if (more) put((chunk + 1) & 1);
+        if (more) {
+            put((chunk + 1) & 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) aw[q] = an[q];
+        }
         __syncthreads();
     }
     const int y = ty0 + (l31 >> 3), x = tx0 + (l31 & 7);
     if (y >= a.H || x >= a.W) return;
-    store_c1(out + (long)b * obs, a.lay, y, x, cb, h2, acc, bias, out_c4);
+    store_c1(out + (long)b * obs, a.lay, y, x, cb, h2, acc, br, out_c4);
 }
 
 // coords (tile-major) -> c1 = relu(convc1(lookup(coords))) (tile-major, 256 channels); wpk / bias: the packed convc1 layer.
@@ -624,6 +646,8 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_kernel(const flo
     const int h2 = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z;
     const long HW = (long)H * W;
+    float br[16];  // this wave's bias, requested before anything that depends on the coordinates
+    load_c1_bias(bias, wave, h2, br);
     // gather role: items tid and tid + 512 of the 64 pixels x 16 runs
     const int vg = tid & 15;
     long pixo[2];   // float offset of the pixel's run at level 0 divided by w2*VG, i.e. the row index b*HW + pix
@@ -706,7 +730,7 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_kernel(const flo
         const int t = blockIdx.x * 2 + p;
         const int y = (t / tiles_x) * 4 + (l31 >> 3), x = (t % tiles_x) * 8 + (l31 & 7);
         if (t >= ntiles || y >= H || x >= W) continue;
-        store_c1(out + (long)b * obs, lay, y, x, wave, h2, p ? acc1 : acc0, bias, out_c4);
+        store_c1(out + (long)b * obs, lay, y, x, wave, h2, p ? acc1 : acc0, br, out_c4);
     }
 }
 
