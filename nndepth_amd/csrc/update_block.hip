@@ -247,6 +247,19 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
     const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
     const long HW = lay.plane;
     const float* src = x + b * xbs;
+    // the finishing threads (tid < 32*FC) request what their last step reads — bias and the state they advance — now, not
+    // behind the reduction at the end of a 7-us kernel
+    float tail_bias = 0.f, tail_state = 0.f;
+    if (tid < 32 * FC) {
+        const int f = tid >> 5, p2 = tid & 31;
+        const int y = ty0 + (p2 >> 3), xx = tx0 + (p2 & 7);
+        tail_bias = bias[f];
+        if (y < H && xx < W) {
+            const long pix = pix_off(lay, y, xx);
+            if (advance == 2) tail_state = flow[(b * FC + f) * HW + pix];
+            else if (advance) tail_state = coords[b * HW + pix];
+        }
+    }
     {
         const int pos = tid & 63, cg = tid >> 6;  // 8 channel groups
         const int gy = ty0 + pos / 10 - 1, gx = tx0 + pos % 10 - 1;
@@ -302,17 +315,17 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
         float sum = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 16; ++sl) sum += part[(sl * FC + f) * 32 + p2];
-        sum += bias[f];
+        sum += tail_bias;
         const int y = ty0 + (p2 >> 3), xx = tx0 + (p2 & 7);
         if (y < H && xx < W) {
             const long pix = pix_off(lay, y, xx);
             delta[(b * FC + f) * HW + pix] = sum;
             if (advance == 2) {  // CREStereo: the state is the flow itself (cre_stereo/model.py:281), any FC
-                const float fl = flow[(b * FC + f) * HW + pix] + sum;
+                const float fl = tail_state + sum;
                 flow[(b * FC + f) * HW + pix] = fl;
                 hx_flow[b * hx_bs + f * (long)hx_cs + pix * hx_pm] = fl;  // hx_cs: floats between the flow channels of the GRU input
             } else if (advance) {  // FC == 1 on this path
-                const float cnew = coords[b * HW + pix] + sum;
+                const float cnew = tail_state + sum;
                 const float fl = absolute ? cnew : cnew - (float)xx;
                 coords[b * HW + pix] = cnew;
                 flow[b * HW + pix] = fl;
