@@ -33,10 +33,14 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 
 DTYPE = {"fp32": "f32", "bf16x3": "f32 carried as 3 bf16 pieces per operand (6 MFMA products, fp32 accumulate)"}
 ARITH_NOTE = {
     "fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every convolution",
-    "bf16x3": "update-block convs except convc1 / mask.2: x = x0+x1+x2, w = w0+w1+w2 in bf16, the 6 products x_i*w_j (i+j<=2) on "
-              "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms <= 2^-24|x||w|); encoder, correlation, lookup, "
-              "convc1, mask.2 + upsample: exact fp32; per-op error vs float64 is BELOW the exact fp32-MFMA kernel's "
-              "(tests/test_gpu_split.py); selectable: --arithmetic fp32"}
+    "bf16x3": "fp32 tensors everywhere; inside the MFMA GEMMs listed here each fp32 operand is carried as 3 bf16 pieces, "
+              "x = x0+x1+x2, w = w0+w1+w2, and the 6 products x_i*w_j (i+j<=2) run on v_mfma_f32_32x32x16_bf16 with fp32 "
+              "accumulation (dropped terms <= 2^-24|x||w|; per-op error vs float64 BELOW the exact fp32-MFMA kernel's, "
+              "tests/test_gpu_split.py): every update-block conv except convc1 (convc2, convf2, conv, the GRU z/r/q convs and their "
+              "context terms, flow_head.conv1 + mask.0, mask.2 inside the fused mask + upsample kernel) and the feature encoder's "
+              "stride-1 3x3 convs + cnet_proj.  Exact fp32 (fp32 MFMA or fp32 VALU): encoder stem, stride-2 convs and 1x1 shortcuts, "
+              "correlation build + lookup + convc1, convf1, flow_head.conv2, softmax + convex upsample, all epilogues.  "
+              "Selectable: --arithmetic fp32 (exact path, also timed in this line as exact_fp32_path)"}
 SPLIT_PRODUCTS = {"fp32": 1, "bf16x3": 6}
 # algorithmic work of one pair: 32 x 43.15 GFLOP loop + 0.5 GFLOP pyramid + 155.2 GFLOP encoder + cnet_proj
 E2E_TFLOP = (32 * 43.15 + 0.5 + 155.2) / 1e3
