@@ -77,8 +77,15 @@ def main():
     ap.add_argument("--config", default="raft544", choices=["raft544", "kitti64", "cre8"],
                     help="raft544 = BASELINE.json configs[1] (the headline, default); kitti64 = configs[3]: 64 KITTI-size pairs "
                          "sharded over the ranks; cre8 = configs[4]: 8 CREStereo 1080x1920 pairs, 2-stage cascade, sharded")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="control-flow check without a GPU (tests/test_dist_cpu.py): ranks meet over gloo, barrier, max over ranks, "
+                         "rank 0 prints a JSON line with the world it saw; no kernel runs and no throughput is reported")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     if args.config != "raft544":
         return sharded_config(args)
     import torch
@@ -264,6 +271,39 @@ def main():
     if world > 1:
         import torch.distributed as dist
         parallel.barrier()  # rank 0's roofline leg runs after the timed region: leave together
+        dist.destroy_process_group()
+
+
+def self_launch(n, argv, backend_env=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run`
+    (one process per GPU, rendezvous on 127.0.0.1) and relay its output — rank 0's JSON line is the last stdout line.
+    Called before anything has touched the GPU or imported torch: this process never initialises HIP and is never
+    replaced (no exec), it only waits for the child and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL on this pool
+    env.update(backend_env or {})
+    log(f"--gpus {n} without WORLD_SIZE: launching {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args):
+    from nndepth_amd import parallel
+    rank, world, local = parallel.init_distributed("gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    parallel.barrier()
+    slowest = parallel.max_over_ranks(1.0 + rank, "cpu")
+    parallel.barrier()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "config": args.config, "max_over_ranks": slowest}))
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -76,16 +76,19 @@ def sharded_inference(n_pairs: int, load_pairs, forward_fn, micro_batch: int, ra
         one all-gather of the rank's disparities at the end -> (n_pairs, C, H, W) in pair order on every rank.
 
     With gather=False the rank-local result is returned (what a caller that only needs its own pairs would use)."""
-    if rank is None or world is None:
-        r, w, _ = env_world()
-        rank, world = (r, w) if rank is None else (rank, world)
+    r, w, _ = env_world()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    # checked on every rank BEFORE any work or collective, so that all ranks raise together instead of the others
+    # hanging in the all-gather
+    if not 0 < world <= n_pairs or not 0 <= rank < world:
+        raise ValueError(f"sharded_inference: rank {rank} / world {world} cannot shard {n_pairs} pairs (need 1 <= world <= n_pairs)")
     mine = list(shard_range(n_pairs, rank, world))
     outs = []
     for i in range(0, len(mine), micro_batch):
         ids = mine[i:i + micro_batch]
         f1, f2 = load_pairs(ids)
         outs.append(forward_fn(f1, f2))
-    assert outs, f"rank {rank} of {world} owns no pair of {n_pairs}: run with world <= n_pairs"
     local = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
     return gather_ragged(local, n_pairs) if gather else local
 

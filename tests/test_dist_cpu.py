@@ -103,3 +103,33 @@ def test_single_process_is_a_noop():
     assert parallel.gather_ragged(y, 3) is y
     got = parallel.sharded_inference(3, lambda ids: (y[ids], y[ids]), lambda a, b: a + b, micro_batch=2, rank=0, world=1)
     assert got[:, 0, 0, 0].tolist() == [0.0, 2.0, 4.0]
+
+
+def test_sharded_inference_rejects_more_ranks_than_pairs_on_every_rank():
+    """the world <= n_pairs check runs before any work or collective and raises the same error on every rank
+    (a rank without pairs used to assert alone while the others waited in the all-gather)."""
+    from nndepth_amd import parallel
+    y = torch.arange(3.0).view(3, 1, 1, 1)
+    for rank in range(4):
+        with pytest.raises(ValueError, match="cannot shard"):
+            parallel.sharded_inference(3, lambda ids: (y[ids], y[ids]), lambda a, b: a + b, micro_batch=1, rank=rank, world=4)
+    # rank given, world resolved from the environment (was: world stayed None)
+    got = parallel.sharded_inference(3, lambda ids: (y[ids], y[ids]), lambda a, b: a + b, micro_batch=2, rank=0)
+    assert got.shape[0] == 3
+
+
+@pytest.mark.parametrize("config", ["raft544", "kitti64"])
+def test_bench_self_launch_world2(config):
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): bench.py starts the two
+    ranks itself as a child torch.distributed.run before touching the GPU; --rendezvous-only stops after the rendezvous,
+    barrier and max-over-ranks on gloo (no GPU here) and rank 0's JSON line comes back through the parent."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--rendezvous-only"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"rendezvous_only": True, "n_gpus": 2, "config": config, "max_over_ranks": 2.0}
