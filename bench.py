@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 H_IMG, W_IMG, ITERS = 544, 960, 32
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-DTYPE = {"fp32": "f32", "bf16x3": "f32 carried as 3 bf16 pieces per operand (6 MFMA products, fp32 accumulate)"}
+DTYPE = {"fp32": "f32", "bf16x3": "f32 carried as 3 bf16 pieces per operand (6 MFMA products, fp32 accumulate)",
+         "fp16x2": "f32 carried as 2 range-scaled fp16 pieces per operand (3 MFMA products, fp32 accumulate)"}
 ARITH_NOTE = {
     "fp32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every convolution",
     "bf16x3": "fp32 tensors everywhere; inside the MFMA GEMMs listed here each fp32 operand is carried as 3 bf16 pieces, "
@@ -41,7 +42,13 @@ ARITH_NOTE = {
               "stride-1 3x3 convs + cnet_proj.  Exact fp32 (fp32 MFMA or fp32 VALU): encoder stem, stride-2 convs and 1x1 shortcuts, "
               "correlation build + lookup + convc1, convf1, flow_head.conv2, softmax + convex upsample, all epilogues.  "
               "Selectable: --arithmetic fp32 (exact path, also timed in this line as exact_fp32_path)"}
-SPLIT_PRODUCTS = {"fp32": 1, "bf16x3": 6}
+ARITH_NOTE["fp16x2"] = (
+    "fp32 tensors everywhere; inside the MFMA GEMMs listed for bf16x3 each fp32 operand is carried as 2 fp16 pieces (22 significand "
+    "bits), x = x0+x1, w = w0+w1, both range-scaled by exact powers of two (activations x4 while staged, weights per layer at pack "
+    "time; undone after the K loop), and the 3 products x0*w0, x0*w1, x1*w0 run on v_mfma_f32_32x32x16_f16 with fp32 accumulation: "
+    "half the matrix work of bf16x3, per-op error vs float64 at the exact fp32-MFMA kernel's level (tests/test_gpu_split.py).  Same "
+    "layer coverage as bf16x3; everything else exact fp32.  Selectable: --arithmetic fp32 | bf16x3")
+SPLIT_PRODUCTS = {"fp32": 1, "bf16x3": 6, "fp16x2": 3}
 # algorithmic work of one pair: 32 x 43.15 GFLOP loop + 0.5 GFLOP pyramid + 155.2 GFLOP encoder + cnet_proj
 E2E_TFLOP = (32 * 43.15 + 0.5 + 155.2) / 1e3
 
@@ -70,7 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hbm-group", action="store_true")
-    ap.add_argument("--arithmetic", default="bf16x3", choices=["bf16x3", "fp32"],
+    ap.add_argument("--arithmetic", default="bf16x3", choices=["bf16x3", "fp16x2", "fp32"],
                     help="MFMA arithmetic of the update-block convolutions: bf16x3 = fp32 operands carried as 3 bf16 pieces, 6 "
                          "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/conv_split.hip; parity-gated, default); "
                          "fp32 = exact fp32 MFMA (csrc/conv_mfma.hip)")
@@ -206,8 +213,9 @@ def main():
             loop_fl += r["gflop"]
         nprod = SPLIT_PRODUCTS[args.arithmetic]  # MFMA FLOPs executed per algorithmic FLOP
         peak = PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS
-        kern = ("conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32)" if nprod == 1 else
-                "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 6 products per fp32 product)")
+        kern = {1: "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                6: "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 6 products per fp32 product)",
+                3: "conv_split_kernel (v_mfma_f32_32x32x16_f16, 3 products per fp32 product)"}[nprod]
         result["roofline"] = {
             "bound": "mfma", "kernel": kern + " — " + dom["conv"],
             "achieved": nprod * dom["tflops_in_loop"], "peak": peak, "unit": "TFLOP/s",

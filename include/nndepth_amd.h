@@ -18,8 +18,9 @@
  *     use distinct streams and distinct output / workspace buffers.  The library keeps no mutable global state:
  *     every kernel of a call — the fused loops' too — is enqueued on the caller's `stream` and nowhere else
  *     (rounds 1-2 ran one branch of the loop on an internal side stream; measured equal, removed);
- *   - diagnostic environment switches (read per call; they select between kernels that the parity tests prove
- *     equivalent, never a non-HIP path): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
+ *   - diagnostic environment switches (read ONCE when the library is loaded and again only by nnd_reload_switches(), never
+ *     on the hot path; they select between kernels that the parity tests prove equivalent, never a non-HIP path; the
+ *     packed-blob layout depends on NND_SPLIT_MASK, so do not reload between a pack and the forwards that use the blob): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
  *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_FUSED_FLOW_BRANCH (convf1 and convf2 as two launches when
  *     arithmetic = 3), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
  *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define NND_VERSION 100 /* 0.1.0 */
+#define NND_VERSION 101 /* 0.1.1: nnd_cre_stereo_refine takes the size of its scratch; nnd_reload_switches */
 
 typedef enum {
     NND_OK = 0,
@@ -53,6 +54,9 @@ int nnd_version(void);
 const char* nnd_last_error(void);
 /* number of visible HIP devices (0 when none / on a CPU-only host); never raises */
 int nnd_device_count(void);
+/* re-reads the NND_* diagnostic switches from the environment (tests and tuning scripts that toggle them in-process);
+ * not to be called concurrently with other entry points */
+int nnd_reload_switches(void);
 
 /* ------------------------------------------------------------------ correlation pyramid
  * Replaces CorrBlock1D.__init__ + CorrBlock1D.corr
@@ -81,7 +85,7 @@ int nnd_corr1d_lookup(const float* pyramid, const float* coords, float* out,
  * Group g correlates channels [g*group_channels, (g+1)*group_channels) of the Ctot-channel maps (the reference
  * uses only the first num_groups chunks of num_groups channels) and divides by sqrt(group_channels).
  * Pyramids use the layout of nnd_corr1d_pyramid_layout(B*num_groups, H, W, num_levels): rows ordered (b,g,h,w1),
- * so level 0 viewed as (B,G,H,W1,W2) is the tensor the 3-D regulariser (PyTorch) consumes.
+ * so level 0 viewed as (B,G,H,W1,W2) is the tensor the 3-D regulariser (nnd_conv3d_*) consumes.
  * nnd_pyramid_from_level0 fills levels 1..num_levels of a pyramid whose level 0 was written by the caller (the
  * regularised volume).  nnd_igev_lookup: coords (B,1,H,W) -> out (B, num_levels*2*G*(2r+1), H, W), channel
  * = i*2*G*T + v*G*T + g*T + k with v = 0 feature / 1 geometry volume.                                   */
@@ -157,7 +161,13 @@ typedef struct {
                               0 = exact fp32 (v_mfma_f32_32x32x2_f32); 3 = every fp32 operand carried as 3 bf16 pieces, the 6
                               products x_i*w_j (i + j <= 2) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms
                               <= 2^-24 |x||w|): per-op error vs float64 below the exact kernel's, RAFT-Stereo 544x960 / 32
-                              iterations vs the reference 4.3e-5 (exact: 3.6e-5).  The packed blob is specific to the value. */
+                              iterations vs the reference 4.3e-5 (exact: 3.6e-5); 2 = every fp32 operand carried as 2 fp16
+                              pieces (22 significand bits), the 3 products x0*w0, x0*w1, x1*w0 on v_mfma_f32_32x32x16_f16 with
+                              fp32 accumulation — half the matrix work of 3; both operands are range-scaled by exact powers of two
+                              (activations x4 while staged, weights per layer at pack time) that the kernel undoes after the K
+                              loop, so the low pieces stay out of fp16's subnormals; valid for activations |x| < 16376 (beyond:
+                              inf / NaN in the output, never a silently wrong value); csrc/split_arith.h.
+                              The packed blob is specific to the value. */
 } nnd_update_block_desc;
 
 /* Number of weight/bias tensors expected by nnd_update_block_pack, in the order of the
@@ -195,7 +205,8 @@ int nnd_conv2d_pack(const float* w_host, const float* b_host, int Cout, int Cin,
 int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
                        int Cout, int KH, int KW, int relu, void* stream);
 /* The same with the arithmetic chosen (see nnd_update_block_desc.arithmetic): 0 = exact fp32 MFMA (identical to the
- * functions above), 3 = fp32 operands as 3 bf16 pieces on the bf16 MFMA (csrc/conv_split.hip; needs Cin % 16 == 0).
+ * functions above), 3 = fp32 operands as 3 bf16 pieces on the bf16 MFMA, 2 = as 2 range-scaled fp16 pieces on the fp16 MFMA
+ * (csrc/conv_split.hip; both need Cin % 16 == 0).
  * The packed blob is specific to the arithmetic it was packed for.                                                  */
 int64_t nnd_conv2d_packed_floats_ex(int Cout, int Cin, int KH, int KW, int arithmetic);
 int nnd_conv2d_pack_ex(const float* w_host, const float* b_host, int Cout, int Cin, int KH, int KW, int arithmetic,
@@ -248,8 +259,8 @@ int nnd_conv_forward(const nnd_conv_desc* desc, const float* packed_dev, const f
  * workspace: nnd_encoder_workspace_floats(desc, N, H, W) floats, caller-owned.                                     */
 typedef struct nnd_encoder_desc {
     int output_dim, norm, cnet_dim;
-    int arithmetic; /* 0 = exact fp32 MFMA; 3 = the stride-1 3x3 convolutions (and cnet_proj) on the bf16 MFMA with 3-piece
-                       split operands (see nnd_update_block_desc.arithmetic); stem, stride-2 and 1x1 layers stay fp32 */
+    int arithmetic; /* 0 = exact fp32 MFMA; 3 / 2 = the stride-1 3x3 convolutions (and cnet_proj) on the 16-bit MFMA with 3 bf16 /
+                       2 fp16 split operands (see nnd_update_block_desc.arithmetic); stem, stride-2 and 1x1 layers stay fp32 */
 } nnd_encoder_desc;
 int nnd_encoder_num_tensors(const nnd_encoder_desc* desc);
 int64_t nnd_encoder_packed_floats(const nnd_encoder_desc* desc);
@@ -298,7 +309,7 @@ int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed_dev, con
  * nnd_conv3d_pack (HOST): w (Cout, Cin0+Cin1, 3, 3, 3), bias / bn_* may be NULL.  leaky_slope 1 = no activation.          */
 typedef struct nnd_conv3d_desc {
     int Cout, Cin0, Cin1, stride;
-    int arithmetic; /* 0 = exact fp32 MFMA; 3 = bf16 MFMA with 3-piece split operands for the stride-1 layers
+    int arithmetic; /* 0 = exact fp32 MFMA; 3 / 2 = 16-bit MFMA with 3 bf16 / 2 fp16 split operands for the stride-1 layers
                        (see nnd_update_block_desc.arithmetic) */
 } nnd_conv3d_desc;
 int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc);
@@ -357,14 +368,18 @@ int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packe
 /* CREStereo variant of the loop — one stage of the cascade (nndepth/models/cre_stereo/model.py:221-236, 246-259, 270-284):
  * every iteration: AGCL correlation of (fmap1, fmap2) at the current flow -> update block (flow_channels = 2) ->
  * flow += delta -> 2-channel convex upsample.  Iteration i searches a 1x9 window when i is even, 3x3 when odd.
- * extra_offset == NULL: iter mode (nnd_agcl_corr_iter; `warped` = caller-owned scratch of B*C*H*W floats);
- * extra_offset (B,18,H,W): offset mode (nnd_agcl_corr_offset; fmap1/fmap2 already attended by the caller; `warped`
- * = scratch of 2*B*C*H*W floats for the channels-last copies of the two maps that nnd_agcl_corr_offset_nhwc samples, or
- * NULL / C != 256: the planar kernel, same results to 1e-7, slower).  flow_init (B,2,H,W) or NULL for zero.
+ * `scratch` = caller-owned device buffer of `scratch_floats` floats (the size is part of the contract: the library checks it
+ * and never writes past it).
+ * extra_offset == NULL: iter mode (nnd_agcl_corr_iter); the scratch receives the warped right map and must hold
+ * B*C*H*W floats (else NND_ERR_INVALID);
+ * extra_offset (B,18,H,W): offset mode (nnd_agcl_corr_offset; fmap1/fmap2 already attended by the caller); with
+ * scratch_floats >= 2*B*C*H*W and C == 256 the two maps are copied channels-last into the scratch once per call and
+ * sampled line by line (nnd_agcl_corr_offset_nhwc); with a smaller / NULL scratch or C != 256: the planar kernel, same
+ * results to 1e-7, slower.  flow_init (B,2,H,W) or NULL for zero.
  * up_out: iteration i writes (B,2,rate*H,rate*W) at up_out + i*up_iter_stride; low_out (optional) the final flow (B,2,H,W); net_out (optional) the hidden state.   */
 int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
-                          const float* fmap1, const float* fmap2, int C, const float* extra_offset, float* warped,
-                          const float* net, const float* inp, const float* flow_init,
+                          const float* fmap1, const float* fmap2, int C, const float* extra_offset,
+                          float* scratch, int64_t scratch_floats, const float* net, const float* inp, const float* flow_init,
                           float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                           float* workspace, int B, int H, int W, int rate, int iters, void* stream);
 

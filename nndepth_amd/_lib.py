@@ -75,7 +75,7 @@ SIGNATURES = {
     "nnd_igev_interleave_pyramids": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_igev_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
-    "nnd_cre_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
+    "nnd_cre_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                    _I, _I, _I, _I, _I, _P]),
     "nnd_conv_packed_floats": (C.c_int64, [C.POINTER(ConvDesc)]),
     "nnd_conv_pack": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.c_float, _P]),
@@ -107,6 +107,7 @@ SIGNATURES = {
     "nnd_profile_loop_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P,
                                    C.POINTER(C.c_float)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),
+    "nnd_reload_switches": (_I, []),
     "nnd_num_convs": (_I, [C.POINTER(UpdateBlockDesc)]),
     "nnd_conv_name": (C.c_char_p, [C.POINTER(UpdateBlockDesc), _I]),
 }

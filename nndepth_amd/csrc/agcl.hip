@@ -453,7 +453,7 @@ int agcl_iter_launch(const float* f1, const float* f2, const float* flow, float*
     hipLaunchKernelGGL(sample_kernel, dim3(cdiv(HW, 256), cdiv(C, SAMPLE_CPB), N), dim3(256), 0, s, f2, (const float*)nullptr,
                        flow, warped, C, H, W, HW, lay);
     NND_LAUNCH_CHECK();
-    if (W % 4 == 0 && !getenv("NND_AGCL_V1")) {
+    if (W % 4 == 0 && !switches().agcl_v1) {
         const dim3 grid(cdiv(HW / 4, 64), 4, N);
         if (small_patch) hipLaunchKernelGGL(window_corr_x4_kernel<true>, grid, dim3(256), 0, s, f1, (const float*)warped, out, C, H, W, lay);
         else hipLaunchKernelGGL(window_corr_x4_kernel<false>, grid, dim3(256), 0, s, f1, (const float*)warped, out, C, H, W, lay);
@@ -478,7 +478,7 @@ int agcl_offset_cl_launch(const float* f1c, const float* f2c, const float* flow,
     NND_REQUIRE(agcl_offset_cl_supported(C), "agcl offset (channels-last): built for %d channels, got %d", CL_C, C);
     NND_REQUIRE((long)H * W * (CL_C / 4) < (1L << 31), "agcl offset (channels-last): offsets exceed 32 bits");
     const Lay lay = make_lay(H, W, tiled);
-    static const int force_pb = getenv("NND_AGCL_PB") ? atoi(getenv("NND_AGCL_PB")) : 0;  // tuning only
+    const int force_pb = switches().agcl_pb;  // tuning only
     if (force_pb == 16)
         hipLaunchKernelGGL(offset_corr_cl_kernel<16>, dim3(cdiv(cdiv(H * W, 16), 8) * 8, 1, N), dim3(256), 0, s, f1c, f2c, flow, extra,
                            out, H, W, small_patch, lay, lay);

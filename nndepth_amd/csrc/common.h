@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include "../../include/nndepth_amd.h"
@@ -35,6 +36,32 @@ void set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+// Diagnostic / tuning switches (NND_* environment variables, listed in include/nndepth_amd.h): read ONCE when the library is
+// loaded and again only by nnd_reload_switches(); the hot path never calls getenv.  They select between kernels that the parity
+// tests prove equivalent, never a non-HIP path.
+struct Switches {
+    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, no_conv1x1_stream,
+        conv_verbose, debug_sync;
+    unsigned split_mask;              // NND_SPLIT_MASK: bit = ConvId of the update-block convs that may take the split kernel
+    int split_ny, split_ks;           // NND_SPLIT_CFG=ny,ks (<= 0: the picker decides)
+    int conv_p, conv_ks, conv_wco;    // NND_CONV_CFG=p,ks,wco / NND_CONV_P
+    int agcl_pb;                      // NND_AGCL_PB
+};
+const Switches& switches();
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on the device's copy of
+// the kernel: once per (call site = kernel instantiation, device).  `done` is the call site's own static bit mask over device ids.
+static inline int raise_lds_limit(const void* kern, std::atomic<unsigned>& done) {
+    int dev = 0;
+    NND_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned bit = 1u << (dev & 31);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        NND_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+    return NND_OK;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -57,8 +84,9 @@ enum ConvEpilogue {
 struct ConvLayer {
     int KH, KW, Cin, Cout, CI_T;  // CI_T: input channels per K-chunk (32, 128 for wide 1x1, 16 for stride 2)
     int stride = 1;               // 1 or 2 ("same" padding K/2; output = ceil(input / stride) for odd K)
-    int arith = 0;                // 0: exact fp32 MFMA (conv_mfma.hip); 3: fp32 carried as 3 bf16 pieces on the bf16 MFMA
-                                  //    (conv_split.hip; CI_T = 16, weights packed as bf16 fragments)
+    int arith = 0;                // 0: exact fp32 MFMA (conv_mfma.hip); 3: fp32 carried as 3 bf16 pieces on the bf16 MFMA; 2: as 2
+                                  //    range-scaled fp16 pieces on the fp16 MFMA (conv_split.hip, split_arith.h; CI_T = 16, weights
+                                  //    packed as 16-bit fragments)
     int64_t s_off = -1;           // float offset of the per-channel scale (EPI_AFFINE), ncb*32 floats; -1: none
     int nchunks;                  // ceil(Cin / CI_T)
     int ncb;                      // ceil(Cout / 32) output-channel blocks
@@ -67,7 +95,7 @@ struct ConvLayer {
         return arith ? (int64_t)ncb * nchunks * KH * KW * arith * 256  // [cb][chunk][tap][piece] x 64 lanes x 16 B
                      : (int64_t)ncb * nchunks * KH * KW * CI_T * 32;
     }
-    int64_t b_floats() const { return (int64_t)ncb * 32; }
+    int64_t b_floats() const { return (int64_t)ncb * 32 + (arith == 2 ? 4 : 0); }  // fp16x2: + the output scale (split_arith.h)
     double flops(int B, int H, int W) const { return 2.0 * B * H * W * (double)Cout * Cin * KH * KW; }
 };
 

@@ -29,6 +29,7 @@ static int conv3d_layer(const nnd_conv3d_desc* d, int J, ConvLayer* L, int64_t* 
     NND_REQUIRE(d, "conv3d: null descriptor");
     NND_REQUIRE(d->Cout > 0 && d->Cin0 > 0 && d->Cin1 >= 0, "conv3d: bad channel counts");
     NND_REQUIRE(d->stride == 1 || d->stride == 2, "conv3d: stride %d not supported (1, 2)", d->stride);
+    NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3 || d->arithmetic == 2, "conv3d: arithmetic must be 0 (fp32 MFMA), 3 (bf16x3) or 2 (fp16x2)");
     ConvLayer l;
     l.KH = l.KW = 3;
     l.Cin = (J + 2) * (d->Cin0 + d->Cin1);
@@ -202,7 +203,7 @@ int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
 
 // the thin (Cout 8 / 16) layers run on thin3d.hip unless NND_NO_THIN3D is set (diagnostic: the MFMA formulations above)
 static bool use_thin(const nnd_conv3d_desc* d) {
-    return getenv("NND_NO_THIN3D") == nullptr && thin3d_supported(d->Cout, d->stride);  // read per call: the tests toggle it
+    return !switches().no_thin3d && thin3d_supported(d->Cout, d->stride);
 }
 
 // 2-D weights of the J-slice grouped layer: (J*Cout, (J+2)*Ct, 3, 3) with [window of input 0: slice-major, ci][window of input 1]

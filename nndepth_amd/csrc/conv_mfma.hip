@@ -413,9 +413,7 @@ struct TileCfg {
 // SIMDs of the chip, so the busiest SIMD runs ceil(waves/1024) * unit (quantisation is what matters at
 // batch 1: 68x120 = 255 tiles of 4x8 pixels).
 static bool pick_tile(const ConvLayer& L, int c0, int c1, int B, int H, int W, TileCfg* out) {
-    int force_p = -1, force_ks = -1, force_wco = -1;
-    if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &force_p, &force_ks, &force_wco);
-    if (const char* e = getenv("NND_CONV_P")) force_p = atoi(e);
+    const int force_p = switches().conv_p, force_ks = switches().conv_ks, force_wco = switches().conv_wco;
     double best = 1e30;
     bool found = false;
     for (int ks : {1, 2})  // ks = 4 measured slower on every layer (scripts/sweep_conv.py)
@@ -477,11 +475,8 @@ template <int KH, int KW, int CI_T, int P, int NE, int STR = 1>
 static int launch_one(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     auto kern = conv_mfma_kernel<KH, KW, CI_T, P, NE, STR>;
     if (lds > 64 * 1024) {
-        static bool raised = false;  // per instantiation; idempotent, so a benign race at worst
-        if (!raised) {
-            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     return NND_OK;
@@ -544,7 +539,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks;
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;
     a.scale = io.scale;
-    static const bool no_stream = getenv("NND_NO_CONV1X1_STREAM") != nullptr;
+    const bool no_stream = switches().no_conv1x1_stream;
     if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && !io.src_c4 && !io.dst_c4 && !io.bmap.ptr &&
         (L.Cin == 64 || L.Cin == 96 || L.Cin == 128) &&
         (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_SCALE || epi == EPI_AFFINE)) {
@@ -556,7 +551,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
         return NND_OK;
     }
     dim3 grid(cfg.tiles_x * cfg.tiles_y, cdiv(L.ncb, cfg.wco), B), block(64 * cfg.wco * cfg.ks);
-    static const bool verbose = getenv("NND_CONV_VERBOSE") != nullptr;
+    const bool verbose = switches().conv_verbose;
     if (verbose)
         fprintf(stderr, "[nnd] conv %dx%d Cin=%d Cout=%d CI_T=%d: P=%d, wco=%d, ks=%d, ne=%d, grid %ux%ux%u, lds %zu B\n",
                 L.KH, L.KW, L.Cin, L.Cout, L.CI_T, cfg.P, cfg.wco, cfg.ks, cfg.ne, grid.x, grid.y, grid.z, cfg.lds);

@@ -29,14 +29,14 @@
 #include "common.h"
 #include "conv_epilogue.h"
 #include "layout.h"
+#include "split_arith.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 namespace nnd {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef NND_SPLIT_AD
 #define NND_SPLIT_AD 1      // steps of lookahead of the weight-fragment stream
@@ -83,23 +83,7 @@ __device__ __forceinline__ int lane_pixel(int l31) {
     return (g0 ? 0 : 16) + idx;
 }
 
-// 8 fp32 -> NS bf16x8 pieces (round-to-nearest of the running residual; the subtractions are exact in fp32)
-template <int NS>
-__device__ __forceinline__ void split_pieces(const float (&x)[8], uint4 (&out)[NS]) {
-    float res[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) res[j] = x[j];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = (__bf16)res[j];
-            res[j] -= (float)v[j];
-        }
-        out[s] = __builtin_bit_cast(uint4, v);
-    }
-}
+// split_pieces<NS> / split_mfma_step<NS>: split_arith.h (NS = 3: bf16 pieces, NS = 2: range-scaled fp16 pieces)
 
 template <int KH, int KW, int NS, int P, int NU>
 __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
@@ -122,6 +106,9 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
     const int Hin = a.Hin, Win = a.Win;
     const long SP = a.ls.plane;
     const int SCH = ks * 16;  // channels per super-chunk
+    // fp16x2: the power-of-two scale that undoes the range scaling of both operands (packed behind the bias), requested now
+    float oscale = 1.f;
+    if constexpr (NS == 2) oscale = a.bias[((a.Cout + 31) >> 5) << 5];
 
     int ty0[P], tx0[P];
 #pragma unroll
@@ -288,16 +275,7 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
 #else
                 if (mine && acc[0][0] == 123.f)
 #endif
-                {
-                    // small products first: x_i * w_j with i + j descending, so they are not absorbed one by one into a
-                    // large partial sum any earlier than necessary
-#pragma unroll
-                    for (int sum = NS - 1; sum >= 0; --sum)
-#pragma unroll
-                        for (int i = 0; i <= sum; ++i)
-                            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[sum - i]),
-                                                                             __builtin_bit_cast(bf16x8, bq[u % NSLOT][i]), acc[pp], 0, 0, 0);
-                }
+                    split_mfma_step<NS>(ac, bq[u % NSLOT], acc[pp]);  // small products first (split_arith.h)
             }
         }
 #ifndef NND_SPLIT_NO_STAGE
@@ -326,6 +304,12 @@ __global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
 
     NND_SSTAMP(2);
     NND_SCLOCK(6);
+    if constexpr (NS == 2) {  // exact: a power of two
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pp][i] *= oscale;
+    }
     int ys[P], xs[P];
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) {
@@ -427,6 +411,18 @@ struct SplitCfg {
 
 constexpr int SPLIT_P = 2, SPLIT_MAX_WAVES = 12;
 
+// fp16x2 pieces on the host: clang's _Float16 conversion is IEEE round-to-nearest-even including subnormal results
+uint16_t f16_rn(float x) {
+    const _Float16 h = (_Float16)x;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+float f16_to_f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
 uint16_t bf16_rn(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -447,8 +443,7 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
     const size_t subb = (size_t)PR * split_row_bytes(PC, NS);
     const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
     const long px_wgs = (long)cdiv(ntiles, SPLIT_P) * B;
-    int force_ny = -1, force_ks = -1;
-    if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d", &force_ny, &force_ks);
+    int force_ny = switches().split_ny, force_ks = switches().split_ks;
     // Short K (Cin <= 64: at most 4 chunks, the encoder's first residual stage): a workgroup is mostly prologue, exchange and
     // epilogue, so the best shape is the smallest one — no split K, all output-channel blocks in one workgroup (the patch is
     // staged once), 6 two-wave workgroups per CU covering each other's fixed phases.  Measured, 64 -> 64 3x3 at 272x480x2
@@ -514,11 +509,8 @@ template <int KH, int KW, int NS, int NU>
 int launch_split_nu(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
     auto kern = conv_split_kernel<KH, KW, NS, SPLIT_P, NU>;
     if (lds > 64 * 1024) {
-        static bool raised = false;  // per instantiation; idempotent, so a benign race at worst
-        if (!raised) {
-            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     return NND_OK;
@@ -531,7 +523,7 @@ int launch_split_one(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 blo
 }  // namespace
 
 bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith) {
-    if (arith != 3 || stride != 1 || Cin % 16 != 0) return false;
+    if ((arith != 3 && arith != 2) || stride != 1 || Cin % 16 != 0) return false;
     return (KH == 3 && KW == 3) || (KH == 1 && KW == 5) || (KH == 5 && KW == 1) || (KH == 1 && KW == 1);
 }
 
@@ -567,22 +559,31 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks; a.npos = cfg.ntiles;
     a.scale = io.scale;
     dim3 grid(cdiv(cfg.ntiles, SPLIT_P), cfg.ny, B), block(64 * cfg.wco * cfg.ks);
-    static const bool verbose = getenv("NND_CONV_VERBOSE") != nullptr;
+    const bool verbose = switches().conv_verbose;
     if (verbose)
         fprintf(stderr, "[nnd] conv_split %dx%d Cin=%d Cout=%d pieces=%d: ny=%d, wco=%d, ks=%d, grid %ux%ux%u, lds %zu B\n", L.KH, L.KW,
                 L.Cin, L.Cout, L.arith, cfg.ny, cfg.wco, cfg.ks, grid.x, grid.y, grid.z, cfg.lds);
     int rc = NND_ERR_UNSUPPORTED;
-    if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 3>(a, cfg, grid, block, stream);
-    else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 3>(a, cfg, grid, block, stream);
-    else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 3>(a, cfg, grid, block, stream);
-    else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 3>(a, cfg, grid, block, stream);
+    if (L.arith == 3) {
+        if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 3>(a, cfg, grid, block, stream);
+        else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 3>(a, cfg, grid, block, stream);
+        else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 3>(a, cfg, grid, block, stream);
+        else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 3>(a, cfg, grid, block, stream);
+    } else {
+        if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 2>(a, cfg, grid, block, stream);
+        else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 2>(a, cfg, grid, block, stream);
+        else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 2>(a, cfg, grid, block, stream);
+        else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 2>(a, cfg, grid, block, stream);
+    }
     if (rc != NND_OK) return rc;
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
 
-// Host packer: same (cout, cin_src, KH, KW) inputs as pack_conv; blob order [cb][chunk][tap][piece][lane][8] bf16 with
-// lane = h*32 + (co % 32) holding channels chunk*16 + 8h + 0..7 (the A operand of v_mfma_f32_32x32x16_bf16).
+// Host packer: same (cout, cin_src, KH, KW) inputs as pack_conv; blob order [cb][chunk][tap][piece][lane][8] 16-bit values with
+// lane = h*32 + (co % 32) holding channels chunk*16 + 8h + 0..7 (the A operand of v_mfma_f32_32x32x16_{bf16,f16}).
+// fp16x2 (arith 2): the pieces are those of w * 2^s, s per layer such that max|w| * 2^s lies in [2^13, 2^14), and the float behind
+// the bias vector (bias[ncb*32]) is oscale = 2^-(s + SPLIT_F16_XSHIFT), which the kernels multiply their accumulators by.
 void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, const float* const* bvec, const int* cout, float* blob,
                      const int* ci_map, int cin_src) {
     if (!ci_map) cin_src = L.Cin;
@@ -591,6 +592,22 @@ void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, cons
     float* bp = blob + L.b_off;
     memset(wp, 0, sizeof(float) * L.w_floats());
     memset(bp, 0, sizeof(float) * L.b_floats());
+    float wscale = 1.f;
+    if (NS == 2) {
+        float wmax = 0.f;
+        for (int part = 0; part < nparts; ++part)
+            for (int col = 0; col < cout[part]; ++col)
+                for (int ci = 0; ci < L.Cin; ++ci)
+                    for (int t = 0; t < NT; ++t) {
+                        const float v = std::fabs(w[part][((size_t)col * cin_src + (ci_map ? ci_map[ci] : ci)) * NT + t]);
+                        if (std::isfinite(v) && v > wmax) wmax = v;
+                    }
+        int e = 0;
+        if (wmax > 0.f) std::frexp(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)  ->  wmax * 2^(14 - e) in [2^13, 2^14)
+        const int s = wmax > 0.f ? 14 - e : 0;
+        wscale = std::ldexp(1.f, s);
+        bp[L.ncb * 32] = std::ldexp(1.f, -(s + SPLIT_F16_XSHIFT));
+    }
     int co0 = 0;
     for (int part = 0; part < nparts; ++part) {
         for (int col = 0; col < cout[part]; ++col) {
@@ -599,10 +616,10 @@ void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, cons
             for (int ci = 0; ci < L.Cin; ++ci) {
                 const int chunk = ci / 16, cl = ci % 16, h = cl / 8, j = cl % 8, lane = h * 32 + i;
                 for (int t = 0; t < NT; ++t) {
-                    float res = w[part][((size_t)col * cin_src + (ci_map ? ci_map[ci] : ci)) * NT + t];
+                    float res = w[part][((size_t)col * cin_src + (ci_map ? ci_map[ci] : ci)) * NT + t] * wscale;
                     for (int s = 0; s < NS; ++s) {
-                        const uint16_t piece = bf16_rn(res);
-                        res -= bf16_to_f(piece);
+                        const uint16_t piece = NS == 2 ? f16_rn(res) : bf16_rn(res);
+                        res -= NS == 2 ? f16_to_f(piece) : bf16_to_f(piece);
                         wp[((((((size_t)cb * L.nchunks + chunk) * NT + t) * NS + s) * 64 + lane) * 8) + j] = piece;
                     }
                 }
@@ -649,16 +666,16 @@ struct FlowBranchArgs {
 };
 
 constexpr int FB_C1 = 128, FB_NCH = FB_C1 / 16, FB_PR = 6, FB_PC = 10, FB_WR = FB_PR + 6, FB_WC = FB_PC + 6;
-__host__ __device__ constexpr int fb_rowb() { return split_row_bytes(FB_PC, 3); }
-__host__ __device__ constexpr int fb_subb() { return FB_PR * fb_rowb(); }
-template <int FC>
+__host__ __device__ constexpr int fb_rowb(int NS) { return split_row_bytes(FB_PC, NS); }
+__host__ __device__ constexpr int fb_subb(int NS) { return FB_PR * fb_rowb(NS); }
+template <int FC, int NS>
 __host__ __device__ constexpr int fb_lds_bytes() {
-    return 4 * (FC * FB_WR * FB_WC + FC * 49 * FB_C1 + FB_C1) + FB_NCH * fb_subb() + 2 * 3 * 1024 * 4;
+    return 4 * (FC * FB_WR * FB_WC + FC * 49 * FB_C1 + FB_C1) + FB_NCH * fb_subb(NS) + 2 * 3 * 1024 * 4;
 }
 
-template <int FC>
+template <int FC, int NS>
 __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
-    constexpr int PS = split_pos_bytes(3), ROWB = fb_rowb(), SUBB = fb_subb();
+    constexpr int PS = split_pos_bytes(NS), ROWB = fb_rowb(NS), SUBB = fb_subb(NS);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* win = reinterpret_cast<float*>(lds_raw);                 // [FC][12][16]
     float* w7l = win + FC * FB_WR * FB_WC;                          // [FC*49][128]
@@ -677,15 +694,17 @@ __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
     // wave = (output block, K slice) of phase 2 — conv_split's wave = kj * wco + cbi with wco = 2, ks = 4.  Its first FB_AD weight
     // fragments are requested NOW: they depend on nothing and arrive while phases 0 and 1 run.
     const int cbi = wave & 1, kj = wave >> 1;
-    const uint4* wq = reinterpret_cast<const uint4*>(a.c.wpk) + (size_t)cbi * FB_NCH * (9 * 3 * 64) + lane;
+    const uint4* wq = reinterpret_cast<const uint4*>(a.c.wpk) + (size_t)cbi * FB_NCH * (9 * NS * 64) + lane;
+    float oscale = 1.f;
+    if constexpr (NS == 2) oscale = a.c.bias[((a.c.Cout + 31) >> 5) << 5];  // undoes the fp16 range scaling (split_arith.h)
     constexpr int NSTEP = (FB_NCH / 4) * 9;  // (chunk, tap) steps of a K slice
     constexpr int FB_AD = 5, NA = FB_AD + 1;
-    uint4 ab[NA][3];
-    auto load_a = [&](uint4 (&dst)[3], int st) {
+    uint4 ab[NA][NS];
+    auto load_a = [&](uint4 (&dst)[NS], int st) {
         const int ch = 4 * (st / 9) + kj, t = st % 9;
-        const uint4* w = wq + (size_t)(ch * 9 + t) * (3 * 64);
+        const uint4* w = wq + (size_t)(ch * 9 + t) * (NS * 64);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) dst[sp] = w[sp * 64];
+        for (int sp = 0; sp < NS; ++sp) dst[sp] = w[sp * 64];
     };
 #pragma unroll
     for (int st = 0; st < FB_AD; ++st) load_a(ab[st], st);
@@ -743,10 +762,10 @@ __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
                 float val[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) val[j] = in ? fmaxf(acc[p][j] + b7l[g * 16 + 8 * h + j], 0.f) : 0.f;
-                uint4 pieces[3];
-                split_pieces<3>(val, pieces);
+                uint4 pieces[NS];
+                split_pieces<NS>(val, pieces);
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < NS; ++sp)
                     *reinterpret_cast<uint4*>(patch + g * SUBB + pr * ROWB + pc * PS + sp * 32 + h * 16) = pieces[sp];
             }
         }
@@ -771,17 +790,16 @@ __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
     for (int st = 0; st < NSTEP; ++st) {
         const int ch = 4 * (st / 9) + kj, t = st % 9;
         if (st + FB_AD < NSTEP) load_a(ab[(st + FB_AD) % NA], st + FB_AD);
-        uint4 bq[3];
+        uint4 bq[NS];
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) bq[sp] = *reinterpret_cast<const uint4*>(xb + ch * SUBB + (t / 3) * ROWB + (t % 3) * PS + sp * 32);
+        for (int sp = 0; sp < NS; ++sp) bq[sp] = *reinterpret_cast<const uint4*>(xb + ch * SUBB + (t / 3) * ROWB + (t % 3) * PS + sp * 32);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch where it is: the scheduler otherwise sinks every load to its use
-#pragma unroll
-        for (int sum = 2; sum >= 0; --sum)
-#pragma unroll
-            for (int i = 0; i <= sum; ++i)
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ab[st % NA][sum - i]),
-                                                                __builtin_bit_cast(bf16x8, bq[i]), acc[0], 0, 0, 0);
+        split_mfma_step<NS>(ab[st % NA], bq, acc[0]);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[0][reg] *= oscale;
     }
 
     NND_FSTAMP(3);
@@ -829,8 +847,17 @@ __global__ void __launch_bounds__(512) flow_branch_kernel(FlowBranchArgs a) {
     NND_FSTAMP(4);
 }
 
+template <int FC, int NS>
+static int launch_fb(const FlowBranchArgs& a, dim3 grid, dim3 block, hipStream_t stream) {
+    auto kern = flow_branch_kernel<FC, NS>;
+    static std::atomic<unsigned> raised{0};
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
+    hipLaunchKernelGGL(kern, grid, block, (fb_lds_bytes<FC, NS>()), stream, a);
+    return NND_OK;
+}
+
 bool flow_branch_supported(const ConvLayer& f2, int fc) {
-    return f2.arith == 3 && f2.KH == 3 && f2.KW == 3 && f2.Cin == FB_C1 && f2.Cout == 64 && f2.stride == 1 && (fc == 1 || fc == 2);
+    return (f2.arith == 3 || f2.arith == 2) && f2.KH == 3 && f2.KW == 3 && f2.Cin == FB_C1 && f2.Cout == 64 && f2.stride == 1 && (fc == 1 || fc == 2);
 }
 
 int launch_flow_branch(const ConvLayer& f2, const float* blob, const float* w7t, const float* b7, const float* flow, int64_t fbs,
@@ -851,23 +878,10 @@ int launch_flow_branch(const ConvLayer& f2, const float* blob, const float* w7t,
     a.c.npos = a.c.tiles_x * cdiv(H, 4);
     a.c.scale = 1.f;
     dim3 grid(a.c.npos, 1, B), block(512);
-    if (fc == 1) {
-        auto kern = flow_branch_kernel<1>;
-        static bool raised = false;
-        if (!raised) {
-            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
-        hipLaunchKernelGGL(kern, grid, block, fb_lds_bytes<1>(), stream, a);
-    } else {
-        auto kern = flow_branch_kernel<2>;
-        static bool raised = false;
-        if (!raised) {
-            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
-        hipLaunchKernelGGL(kern, grid, block, fb_lds_bytes<2>(), stream, a);
-    }
+    int rc;
+    if (fc == 1) rc = f2.arith == 3 ? launch_fb<1, 3>(a, grid, block, stream) : launch_fb<1, 2>(a, grid, block, stream);
+    else rc = f2.arith == 3 ? launch_fb<2, 3>(a, grid, block, stream) : launch_fb<2, 2>(a, grid, block, stream);
+    if (rc != NND_OK) return rc;
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

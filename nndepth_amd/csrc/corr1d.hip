@@ -265,22 +265,20 @@ static bool corr1d_build_lds_launch(const float* f1, const float* f2, float* pyr
     const int ntile = cdiv(W, 32), WP = ntile * 32, NT = cdiv(ntile, 4);
     int KC = C >= 32 ? 32 : ((C + 1) / 2) * 2;
     if (C >= 64 && cdiv(64 * (8 + WP / 4), 256) <= CB_MAXLD) KC = 64;  // fewer, longer chunks: the next chunk's loads get more cover
-    if (NT > 4 || cdiv(KC * (8 + WP / 4), 256) > CB_MAXLD || getenv("NND_CORR_BUILD_V1")) return false;
+    if (NT > 4 || cdiv(KC * (8 + WP / 4), 256) > CB_MAXLD || switches().corr_build_v1) return false;
     long outf = 0;
     for (int l = 0; l < L.nlev; ++l) outf += 32L * L.width[l];
     const size_t lds = sizeof(float) * (size_t)std::max<long>((long)KC * (32 + WP), outf);
     if (lds > 160 * 1024) return false;
     dim3 grid(cdiv(W, 32), H, B * G), block(256);
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
-    if (!attr_set) {
+    {  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and device
+        static std::atomic<unsigned> raised[4];
         const void* kerns[4] = {reinterpret_cast<const void*>(corr1d_build_lds_kernel<1>), reinterpret_cast<const void*>(corr1d_build_lds_kernel<2>),
                                 reinterpret_cast<const void*>(corr1d_build_lds_kernel<3>), reinterpret_cast<const void*>(corr1d_build_lds_kernel<4>)};
-        for (const void* k : kerns)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                *rc = NND_ERR_HIP;
-                return true;
-            }
-        attr_set = true;
+        if (raise_lds_limit(kerns[NT - 1], raised[NT - 1]) != NND_OK) {
+            *rc = NND_ERR_HIP;
+            return true;
+        }
     }
     if (NT == 1) hipLaunchKernelGGL(corr1d_build_lds_kernel<1>, grid, block, lds, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, KC);
     else if (NT == 2) hipLaunchKernelGGL(corr1d_build_lds_kernel<2>, grid, block, lds, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, KC);
@@ -748,12 +746,8 @@ int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, co
     make_il_layout(B, G, H, W, num_levels, &IL, nullptr);
     NND_REQUIRE(IL.width[num_levels - 1] >= 2, "igev_lookup_convc1: level %d has width %d < 2", num_levels - 1, IL.width[num_levels - 1]);
     const size_t lds = 2 * IL_LC * IL_S * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(igev_lookup_convc1_il_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<unsigned> raised{0};
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(igev_lookup_convc1_il_kernel), raised)) return rc;
     const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
     const int cb_stride = L.nchunks * (L.CI_T / 8) * 64;
     hipLaunchKernelGGL(igev_lookup_convc1_il_kernel, dim3(cdiv(ntiles, 2), 1, B), dim3(512), lds, stream, il, coords, blob + L.w_off,

@@ -281,6 +281,7 @@ static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
     NND_REQUIRE(d, "encoder: null descriptor");
     NND_REQUIRE(d->output_dim > 0 && d->cnet_dim >= 0, "encoder: bad output_dim / cnet_dim");
     NND_REQUIRE(d->norm >= 0 && d->norm <= 2, "encoder: norm must be 0 (none), 1 (batch, eval) or 2 (instance); group norm is not built");
+    NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3 || d->arithmetic == 2, "encoder: arithmetic must be 0 (fp32 MFMA), 3 (bf16x3) or 2 (fp16x2)");
     p->d = *d;
     int64_t off = 0;
     p->stem_w = off; off += STEM_K * 64;

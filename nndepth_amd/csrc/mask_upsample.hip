@@ -12,19 +12,19 @@
 //   * the two K-halves are summed into an LDS mask tile [9*R*R][33]; then every thread produces output pixels:
 //     9 logits from LDS -> softmax -> weighted sum of the 3x3 flow neighbourhood -> R*8 contiguous floats per
 //     (tile row, sub-row) so the HBM stores are whole 256-B runs.
-// SPLIT = true (arithmetic 3, round 2): the same GEMM with both operands as 3 bf16 pieces and 6 products per fp32 product on
-// v_mfma_f32_32x32x16_bf16 (conv_split.hip's arithmetic; weights in its packing).  Phase stamps of the exact kernel at 68x120
+// NS = 3 (arithmetic 3, round 2): the same GEMM with both operands as 3 bf16 pieces and 6 products per fp32 product on
+// v_mfma_f32_32x32x16_bf16 (conv_split.hip's arithmetic; weights in its packing); NS = 2 (arithmetic 2, round 3): 2 range-scaled
+// fp16 pieces, 3 products on v_mfma_f32_32x32x16_f16 (split_arith.h); NS = 0: the exact fp32 MFMA.  Phase stamps of the exact kernel at 68x120
 // (scripts/stamps_mu.py): stage 3.8 us, K loop 22 (2.4 GFLOP on the fp32 MFMA = 15.3 us at peak: the kernel is matrix-bound),
 // softmax + store 3.2.  The x tile is staged as [16-ch chunk][piece][k half][pixel][8 bf16], so a B fragment is one
 // conflict-free ds_read_b128 per piece, shared by the wave's 3 output-channel blocks.
 #include "common.h"
 #include "layout.h"
+#include "split_arith.h"
 
 namespace nnd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef NND_DBG_STAMPS
 // debug build only (scripts/build_ablate.sh): per-workgroup phase timestamps, s_memrealtime at 100 MHz
@@ -63,8 +63,9 @@ struct MaskUpCfg {
     static constexpr int LDS_FLOATS = (XS_FLOATS > COUT * MT_STRIDE ? XS_FLOATS : COUT * MT_STRIDE) + 128;
 };
 
-template <int RATE, int CIN, bool SPLIT = false>
+template <int RATE, int CIN, int NS = 0>
 __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kernel(MaskUpArgs a) {
+    constexpr bool SPLIT = NS != 0;
     using Cfg = MaskUpCfg<RATE, CIN>;
     constexpr int COUT = Cfg::COUT, NCB = Cfg::NCB, CBW = Cfg::CBW, G = Cfg::G, NT = Cfg::NT, NST = Cfg::NST;
     constexpr int CI_T = 128;                 // packing of a 1x1 conv with Cin >= 128 (conv_ci_t)
@@ -86,12 +87,14 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     const int H = a.H, W = a.W;
     const long HW = (long)H * W;
     const long XP = a.lay.plane;
+    float oscale = 1.f;  // fp16x2: undoes the power-of-two range scaling of both operands (packed behind the bias)
+    if constexpr (NS == 2) oscale = a.bias[Cfg::NCB * 32];
 
     // ---- stage the x tile (all CIN channels) and the flow patch
     {
         const float* src = a.x + b * a.xbs;
         if constexpr (SPLIT) {
-            // item = (pixel, 4 consecutive channels): one 16-B load (c4) or four 4-B loads, split into 3 x 4 bf16 = three 8-B stores
+            // item = (pixel, 4 consecutive channels): one 16-B load (c4) or four 4-B loads, split into NS x 4 16-bit pieces = NS 8-B stores
             unsigned char* xsb = reinterpret_cast<unsigned char*>(lds);
             constexpr int NQ4 = (CIN / 4 * 32 + NT - 1) / NT;
             float4 v4[NQ4];
@@ -114,19 +117,14 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
                 const int qd = e >> 5, px = e & 31;
                 const bool ok = (ty0 + (px >> 3)) < H && (tx0 + (px & 7)) < W;
                 if (e < CIN / 4 * 32) {
-                    float res[4] = {ok ? v4[i].x : 0.f, ok ? v4[i].y : 0.f, ok ? v4[i].z : 0.f, ok ? v4[i].w : 0.f};
+                    const float res[4] = {ok ? v4[i].x : 0.f, ok ? v4[i].y : 0.f, ok ? v4[i].z : 0.f, ok ? v4[i].w : 0.f};
                     const int chunk = qd >> 2, sub = qd & 3;
+                    constexpr int NP = NS == 0 ? 3 : NS;
+                    uint2 pv[NP];
+                    split_pieces_n<NP, 4, uint2>(res, pv);  // round-to-nearest of the running residual (split_arith.h)
 #pragma unroll
-                    for (int sp = 0; sp < 3; ++sp) {  // round-to-nearest of the running residual; the subtractions are exact
-                        bf16x4 pv;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            pv[j] = (__bf16)res[j];
-                            res[j] -= (float)pv[j];
-                        }
-                        *reinterpret_cast<uint2*>(xsb + ((((chunk * 3 + sp) * 2 + (sub >> 1)) * 32 + px) * 16 + (sub & 1) * 8)) =
-                            __builtin_bit_cast(uint2, pv);
-                    }
+                    for (int sp = 0; sp < NP; ++sp)
+                        *reinterpret_cast<uint2*>(xsb + ((((chunk * NP + sp) * 2 + (sub >> 1)) * 32 + px) * 16 + (sub & 1) * 8)) = pv[sp];
                 }
             }
         } else
@@ -189,7 +187,8 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     if constexpr (SPLIT) {
-        // weights in pack_conv_split order: uint4 index (((cb * NCH16 + chunk) * 3 + piece) * 64 + lane), lane = k-half * 32 + (co % 32)
+        // weights in pack_conv_split order: uint4 index (((cb * NCH16 + chunk) * NP + piece) * 64 + lane), lane = k-half * 32 + (co % 32)
+        constexpr int NP = NS == 0 ? 3 : NS;
         constexpr int NCH16 = CIN / 16, CPW = NCH16 / 2;  // 16-channel chunks: all / per wave (its K half)
         const uint4* wq4 = reinterpret_cast<const uint4*>(a.wpk);
         const unsigned char* xsb = reinterpret_cast<const unsigned char*>(lds);
@@ -197,22 +196,22 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
         auto a_ptr = [&](int cbi, int ch) {
             int cb = g * CBW + cbi;
             cb = cb < NCB ? cb : NCB - 1;  // padded group member: re-reads a valid block, result discarded
-            return wq4 + (size_t)((cb * NCH16 + c0k + ch) * 3) * 64 + lane;
+            return wq4 + (size_t)((cb * NCH16 + c0k + ch) * NP) * 64 + lane;
         };
         // a unit (chunk, block) is only 6 MFMAs = 192 cycles: the weight fragments run AD units ahead through a ring of AD + 1
         // register sets.  (AD = 1 measured the same 22.4 us: the 255 workgroups pull 864 KB of weight pieces each = 220 MB per
         // launch through the L2s, ~18 TB/s during the K loop — the stream is throughput-bound, not latency-bound.)
         constexpr int AD = 3, NA = AD + 1, NUNIT = CPW * CBW;
-        uint4 ab[NA][3], bq[2][3];
+        uint4 ab[NA][NP], bq[2][NP];
         auto load_a = [&](uint4* dst, int u) {
             const uint4* w = a_ptr(u % CBW, u / CBW);
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) dst[sp] = w[sp * 64];
+            for (int sp = 0; sp < NP; ++sp) dst[sp] = w[sp * 64];
         };
         auto load_b = [&](uint4* dst, int ch) {
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
-                dst[sp] = *reinterpret_cast<const uint4*>(xsb + (((((c0k + ch) * 3 + sp) * 2 + h2) * 32 + l31) * 16));
+            for (int sp = 0; sp < NP; ++sp)
+                dst[sp] = *reinterpret_cast<const uint4*>(xsb + (((((c0k + ch) * NP + sp) * 2 + h2) * 32 + l31) * 16));
         };
 #pragma unroll
         for (int u = 0; u < AD && u < NUNIT; ++u) load_a(ab[u], u);
@@ -223,14 +222,14 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             if (u + AD < NUNIT) load_a(ab[(u + AD) % NA], u + AD);
             if (cbi == 0 && ch + 1 < CPW) load_b(bq[(ch + 1) & 1], ch + 1);
             __builtin_amdgcn_sched_barrier(0);
-            // x_i * w_j with i + j descending: the small products first (conv_split.hip)
-#pragma unroll
-            for (int sum = 2; sum >= 0; --sum)
-#pragma unroll
-                for (int i = 0; i <= sum; ++i)
-                    acc[cbi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ab[u % NA][sum - i]),
-                                                                     __builtin_bit_cast(bf16x8, bq[ch & 1][i]), acc[cbi], 0, 0, 0);
+            split_mfma_step<NP>(ab[u % NA], bq[ch & 1], acc[cbi]);  // x_i * w_j with i + j descending: the small products first
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NS == 2) {
+#pragma unroll
+            for (int cbi = 0; cbi < CBW; ++cbi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cbi][r] *= oscale;
         }
     } else {
         constexpr int SPW = NST / 2;  // steps per wave
@@ -334,17 +333,14 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     NND_MSTAMP(4);
 }
 
-template <int RATE, int CIN, bool SPLIT = false>
+template <int RATE, int CIN, int NS = 0>
 static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
     using Cfg = MaskUpCfg<RATE, CIN>;
-    auto kern = mask_upsample_kernel<RATE, CIN, SPLIT>;
+    auto kern = mask_upsample_kernel<RATE, CIN, NS>;
     const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
     }
     dim3 grid(a.tiles_x * cdiv(a.H, 4), 1, B), block(Cfg::NT);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
@@ -358,7 +354,7 @@ bool mask_upsample_supported(int rate, int cin, int flow_channels) {
 
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
                          int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels, bool x_c4) {
-    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == (L.arith ? 16 : 128) && L.Cout == 9 * rate * rate && (L.arith == 0 || L.arith == 3),
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == (L.arith ? 16 : 128) && L.Cout == 9 * rate * rate && (L.arith == 0 || L.arith == 3 || L.arith == 2),
                 "mask_upsample: layer shape / packing");
     NND_REQUIRE(mask_upsample_supported(rate, L.Cin, flow_channels), "mask_upsample: rate %d / Cin %d / %d flow channels not built",
                 rate, L.Cin, flow_channels);
@@ -368,10 +364,16 @@ int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, 
     a.lay = make_lay(H, W, tiled);
     a.x_c4 = (tiled && x_c4) ? 1 : 0;
     if (L.arith == 3) {  // split-bf16 arithmetic: weights in pack_conv_split's order
-        if (rate == 8 && L.Cin == 256) return launch_mu<8, 256, true>(a, B, stream);
-        if (rate == 8 && L.Cin == 128) return launch_mu<8, 128, true>(a, B, stream);
-        if (rate == 4 && L.Cin == 256) return launch_mu<4, 256, true>(a, B, stream);
-        return launch_mu<4, 128, true>(a, B, stream);
+        if (rate == 8 && L.Cin == 256) return launch_mu<8, 256, 3>(a, B, stream);
+        if (rate == 8 && L.Cin == 128) return launch_mu<8, 128, 3>(a, B, stream);
+        if (rate == 4 && L.Cin == 256) return launch_mu<4, 256, 3>(a, B, stream);
+        return launch_mu<4, 128, 3>(a, B, stream);
+    }
+    if (L.arith == 2) {  // range-scaled fp16 pieces
+        if (rate == 8 && L.Cin == 256) return launch_mu<8, 256, 2>(a, B, stream);
+        if (rate == 8 && L.Cin == 128) return launch_mu<8, 128, 2>(a, B, stream);
+        if (rate == 4 && L.Cin == 256) return launch_mu<4, 256, 2>(a, B, stream);
+        return launch_mu<4, 128, 2>(a, B, stream);
     }
     if (rate == 8 && L.Cin == 256) return launch_mu<8, 256>(a, B, stream);
     if (rate == 8 && L.Cin == 128) return launch_mu<8, 128>(a, B, stream);

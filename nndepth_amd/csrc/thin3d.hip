@@ -169,11 +169,8 @@ static int launch_thin(const Thin3dArgs& a, int N, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "thin3d slab");
     auto kern = thin_conv3d_kernel<COUT, STR>;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            NND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
     }
     dim3 grid(cdiv(a.Wo, T3_TX) * cdiv(a.Ho, T3_TY), cdiv(a.Do, T3_TZ), N);
     NND_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "thin_conv3d: volume too deep for the grid");

@@ -65,12 +65,14 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     NND_REQUIRE(ctx > 0 && ctx % 8 == 0, "update_block: context_dim %d must be a positive multiple of 8", ctx);
     NND_REQUIRE(cp > 0 && (fc == 1 || fc == 2) && mc > 0 && mc % 9 == 0, "update_block: bad cor_planes/flow_channels/mask_channels");
     NND_REQUIRE(d->gru_kind == 0 || d->gru_kind == 1, "update_block: gru_kind must be 0 (sep_conv) or 1 (conv_gru)");
-    NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3, "update_block: arithmetic must be 0 (fp32 MFMA) or 3 (bf16x3 split)");
+    NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3 || d->arithmetic == 2,
+                "update_block: arithmetic must be 0 (fp32 MFMA), 3 (bf16x3 split) or 2 (fp16x2 split)");
     // arithmetic == 3: every MFMA conv whose shape conv_split.hip builds takes the split-bf16 kernel (mask.2 inside the fused
-    // mask + upsample kernel), except convc1 (its weights are consumed by the fused lookup kernels in the fp32 packing) and convf2; NND_SPLIT_MASK (diagnostic)
-    // restricts it to a subset, bit = ConvId (e.g. 2 = encoder.convc2 only)
-    unsigned split_mask = ~0u;
-    if (const char* e = getenv("NND_SPLIT_MASK")) split_mask = (unsigned)strtoul(e, nullptr, 0);
+    // mask + upsample kernel; convf2 together with convf1 in flow_branch_kernel), except convc1 (its weights are consumed by the
+    // fused lookup kernels in the fp32 packing); NND_SPLIT_MASK (diagnostic) restricts it to a subset, bit = ConvId (e.g. 2 =
+    // encoder.convc2 only)
+    // (read once at library load, so the packed-blob layout cannot change between pack and forward)
+    const unsigned split_mask = switches().split_mask;
     auto ar = [&](int id) { return (d->arithmetic != 0 && ((split_mask >> id) & 1u)) ? d->arithmetic : 0; };
     p->d = *d;
     p->sep = d->gru_kind == 0;
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
 static Act act(float* p, int64_t bs, int C) { return Act{p, bs, C}; }
 
 // 4-channel-interleaved layout of the conv-only workspace tensors (layout.h); NND_NO_C4 (diagnostic) keeps them planar
-static bool ws_c4() { return getenv("NND_NO_C4") == nullptr; }
+static bool ws_c4() { return !switches().no_c4; }
 // float offset of channel c / floats between consecutive pixels of a workspace tensor with plane size n
 static int64_t ws_chan(int c, int64_t n) { return ws_c4() ? (int64_t)(c / 4) * 4 * n + c % 4 : (int64_t)c * n; }
 static int ws_pm() { return ws_c4() ? 4 : 1; }
@@ -437,8 +439,7 @@ static int conv_epi(int id) {
 
 // NND_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault localisation only).
 static int debug_sync(const char* what, hipStream_t s) {
-    static const bool on = getenv("NND_DEBUG_SYNC") != nullptr;
-    if (!on) return NND_OK;
+    if (!switches().debug_sync) return NND_OK;
     fprintf(stderr, "[nnd] %s ...", what);
     fflush(stderr);
     NND_HIP_CHECK(hipStreamSynchronize(s));
@@ -499,7 +500,7 @@ static int run_flow_branch(const Plan& p, const float* blob, const Bufs& w, cons
                            hipStream_t s) {
     const int fc = p.d.flow_channels;
     const int64_t n = tiled_plane(H, W);
-    if (flow_branch_supported(p.L[C_F2], fc) && !getenv("NND_NO_FUSED_FLOW_BRANCH")) {
+    if (flow_branch_supported(p.L[C_F2], fc) && !switches().no_fused_flow_branch) {
         const ConvIO io = conv_io(p, w, C_F2, corr, n, nullptr, nullptr);
         int rc = launch_flow_branch(p.L[C_F2], blob, blob + p.f1_wt, blob + p.f1_b, flow, (int64_t)fc * n, fc, io, B, H, W, s);
         if (rc != NND_OK) return rc;
@@ -681,7 +682,8 @@ struct CreArgs {
     const float* f1;
     const float* f2;
     const float* extra;
-    float* warped;
+    float* warped;           // caller-owned scratch
+    int64_t warped_floats;   // its size: >= B*C*H*W in iter mode; >= 2*B*C*H*W selects the channels-last offset kernel
     int C;
 };
 
@@ -717,6 +719,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     if (cre) {
         NND_REQUIRE(fc == 2 && p.d.cor_planes == 36, "cre_stereo_refine: needs flow_channels 2 and cor_planes 36");
         NND_REQUIRE(cre->f1 && cre->f2 && (cre->extra || cre->warped), "cre_stereo_refine: null feature map / scratch");
+        NND_REQUIRE(cre->extra || cre->warped_floats >= (int64_t)B * cre->C * H * W,
+                    "cre_stereo_refine: iter mode needs a scratch of B*C*H*W = %lld floats, got %lld", (long long)B * cre->C * H * W,
+                    (long long)cre->warped_floats);
     } else {
         NND_REQUIRE(fc == 1, "raft_stereo_refine: flow_channels must be 1");
         NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1) * (igev ? 2 * groups : 1),
@@ -749,7 +754,10 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         NND_LAUNCH_CHECK();
     }
     // offset mode with a scratch: channels-last copies of the two maps, made once for all iterations of the stage
-    const bool cre_cl = cre && cre->extra && cre->warped && agcl_offset_cl_supported(cre->C) && !getenv("NND_AGCL_V1");
+    // (explicit opt-in by size: a scratch smaller than 2*B*C*H*W floats — e.g. a caller reusing its iter-mode scratch — takes the
+    //  planar offset kernel instead of being written past its end)
+    const bool cre_cl = cre && cre->extra && cre->warped && cre->warped_floats >= 2 * (int64_t)B * cre->C * H * W &&
+                        agcl_offset_cl_supported(cre->C) && !switches().agcl_v1;
     if (cre_cl) {
         NND_TRY(nchw_to_nhwc_launch(cre->f1, cre->warped, B, cre->C, H * W, s));
         NND_TRY(nchw_to_nhwc_launch(cre->f2, cre->warped + (int64_t)B * cre->C * H * W, B, cre->C, H * W, s));
@@ -780,8 +788,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     // shared stream pool, and the in-loop time of a kernel is its stand-alone time.  Earlier measurements (round 1, ms
     // per pair): a third stream for the mask branch 18.0 vs 17.6 | the linear schedule as a hipGraph 17.6 vs 17.6 |
     // the 3-stream DAG as a hipGraph 34.
-    const bool no_fuse_up = getenv("NND_NO_FUSED_UPSAMPLE") != nullptr;  // read per call: the parity tests toggle these
-    const bool no_fuse_lk = getenv("NND_NO_FUSED_LOOKUP") != nullptr;
+    const bool no_fuse_up = switches().no_fused_upsample;  // the parity tests toggle these (nnd_reload_switches)
+    const bool no_fuse_lk = switches().no_fused_lookup;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     const bool fused_lk = !cre && !no_fuse_lk;
     // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
@@ -916,14 +924,15 @@ int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packe
 }
 
 int nnd_cre_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* fmap1, const float* fmap2,
-                          int C, const float* extra_offset, float* warped, const float* net, const float* inp,
+                          int C, const float* extra_offset, float* scratch, int64_t scratch_floats, const float* net, const float* inp,
                           const float* flow_init, float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                           float* workspace, int B, int H, int W, int rate, int iters, void* stream) {
     NND_REQUIRE(fmap1 && fmap2, "cre_stereo_refine: null feature map");
-    NND_REQUIRE(extra_offset || warped, "cre_stereo_refine: iter mode (extra_offset == NULL) needs the warped scratch");
+    NND_REQUIRE(extra_offset || scratch, "cre_stereo_refine: iter mode (extra_offset == NULL) needs the scratch for the warped map");
+    NND_REQUIRE(scratch_floats >= 0 && (scratch || scratch_floats == 0), "cre_stereo_refine: scratch_floats without a scratch");
     int rc = agcl_check("cre_stereo_refine", B, C, H, W);
     if (rc != NND_OK) return rc;
-    CreArgs cre{fmap1, fmap2, extra_offset, warped, C};
+    CreArgs cre{fmap1, fmap2, extra_offset, scratch, scratch_floats, C};
     return enqueue_refine(desc, packed, nullptr, 0, 0, net, inp, flow_init, up_out, up_iter_stride, low_out, net_out, workspace,
                           B, H, W, rate, iters, stream, nullptr, 1, &cre);
 }

@@ -193,14 +193,15 @@ def update_block_keys(gru: str = "sep_conv") -> List[str]:
 class UpdateBlockEngine:
     """Packed parameters + workspace for one BasicUpdateBlock configuration."""
 
-    ARITHMETIC = {"fp32": 0, "bf16x3": 3}
+    ARITHMETIC = {"fp32": 0, "bf16x3": 3, "fp16x2": 2}
 
     def __init__(self, hidden_dim: int, context_dim: int, cor_planes: int, flow_channels: int,
                  mask_channels: int, gru: str = "sep_conv", arithmetic: str = "fp32"):
         if gru not in ("sep_conv", "conv_gru"):
             raise NndError(f"unknown gru kind {gru!r}")
         if arithmetic not in self.ARITHMETIC:
-            raise NndError(f"unknown arithmetic {arithmetic!r} (fp32 = exact fp32 MFMA, bf16x3 = 3-piece split on the bf16 MFMA)")
+            raise NndError(f"unknown arithmetic {arithmetic!r} (fp32 = exact fp32 MFMA, bf16x3 = 3-piece split on the bf16 MFMA, "
+                           "fp16x2 = 2-piece range-scaled split on the fp16 MFMA)")
         self.gru = gru
         self.arithmetic = arithmetic
         self.desc = UpdateBlockDesc(hidden_dim, context_dim, cor_planes, flow_channels, mask_channels,
@@ -364,7 +365,7 @@ class UpdateBlockEngine:
             scratch = torch.empty(need, dtype=torch.float32, device=d)
         with torch.cuda.device(d):
             check(lib.nnd_cre_stereo_refine(C.byref(self.desc), _p(self.packed), _p(fmap1), _p(fmap2), Cf, _p(extra_offset),
-                                            _p(scratch), _p(net), _p(inp), _p(flow_init), _p(up), stride, _p(low),
+                                            _p(scratch), scratch.numel(), _p(net), _p(inp), _p(flow_init), _p(up), stride, _p(low),
                                             _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "cre_stereo_refine")
         return up, low, net_out
 

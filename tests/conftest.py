@@ -15,6 +15,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with one addition: the library reads its NND_* diagnostic switches once at load
+    (nnd_reload_switches re-reads them), so setting / deleting one through this fixture also makes the library re-read them,
+    and they are re-read once more after the environment has been restored."""
+    from nndepth_amd._lib import lib
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("NND_"):
+            lib.nnd_reload_switches()
+
+    def delenv_(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("NND_"):
+            lib.nnd_reload_switches()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_, delenv_
+    yield monkeypatch
+    monkeypatch.undo()
+    lib.nnd_reload_switches()
+
+
 @pytest.fixture(scope="session")
 def gold():
     def load(name):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/nndepth_amd.h but not exported"
     assert set(_lib.SIGNATURES) == set(syms), "ctypes table and header out of sync"
-    assert _lib.lib.nnd_version() == 100
+    assert _lib.lib.nnd_version() == 101
     assert _lib.lib.nnd_device_count() >= 0  # must not raise / abort on a CPU-only host
 
 
@@ -196,7 +196,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.nnd_encoder_packed_floats(C.byref(e)) < 0
     assert lib.nnd_encoder_forward(C.byref(EncoderDesc(256, 1, 0)), None, None, None, None, 0, None, 2, 64, 64, None) < 0
     u = UpdateBlockDesc(128, 128, 36, 2, 576, 0)
-    assert lib.nnd_cre_stereo_refine(C.byref(u), None, None, None, 256, None, None, None, None, None, None, 0, None, None, None,
+    assert lib.nnd_cre_stereo_refine(C.byref(u), None, None, None, 256, None, None, 0, None, None, None, None, 0, None, None, None,
                                      1, 8, 8, 8, 2, None) < 0
 
 

@@ -90,7 +90,7 @@ def test_igev_config3_136x240_vs_oracle(R, B):
     del got_lk
     # loop: 2 iterations from the oracle's initial disparity (isolates the loop from the init error above)
     # (both arithmetics: 32 640 pixels = 510 workgroup columns, the split kernel's large-map workgroup shapes)
-    for ar in ("fp32", "bf16x3"):
+    for ar in ("fp32", "bf16x3", "fp16x2"):
         ub = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4, arithmetic=ar)
         ub.load_state_dict({k[len("update_block."):]: v for k, v in ub_sd.items()})
         eng = ub.to(DEV).sync_engine(DEV)
@@ -120,7 +120,7 @@ def test_raft_config4_kitti_batch8_vs_oracle(raft_sd, R):
     padder = Padder((375, 1242), divis_by=32)
     p1, p2 = padder.pad(f1.to(DEV), f2.to(DEV))
     assert tuple(p1.shape) == (Bn, 3, 384, 1248)
-    for ar in ("fp32", "bf16x3"):  # batch 8 = 960 workgroup columns: the split kernel's large-map workgroup shapes
+    for ar in ("fp32", "bf16x3", "fp16x2"):  # batch 8 = 960 workgroup columns: the split kernel's large-map workgroup shapes
         m = BaseRAFTStereo(iters=iters, context_dim=64, arithmetic=ar)
         m.load_state_dict(raft_sd, strict=True)
         m = m.to(DEV).eval()
@@ -145,7 +145,7 @@ def test_cre_config5_1080x1920_vs_oracle(cre_sd):
     fr1, fr2 = weightgen.synthetic_frames(13, 1, 1080, 1920)
     with torch.no_grad():
         exp = CR.cre_stereo_forward(cre_sd, fr1, fr2, 2)
-    for ar in ("fp32", "bf16x3"):
+    for ar in ("fp32", "bf16x3", "fp16x2"):
         m = CREStereoBase(iters=2, arithmetic=ar)
         m.load_state_dict(cre_sd, strict=True)
         m = m.to(DEV).eval()

@@ -91,7 +91,7 @@ def test_corr1d_fullsize_vs_oracle_and_properties(ops, R):
     assert (out - exp).abs().max() <= 5e-5
 
 
-def test_corr1d_edge_cases(ops):
+def test_corr1d_edge_cases(ops, monkeypatch):
     # ragged width (not a multiple of 32), odd pooling tails, B>1, tiny C
     f1, f2 = torch.randn(3, 2, 3, 33), torch.randn(3, 2, 3, 33)
     from oracle import torch_ref as R
@@ -115,11 +115,9 @@ def test_corr1d_edge_cases(ops):
         for i, (o, w) in enumerate(zip(offs, widths)):
             mine = pyr[o:o + B * H * W * w].view(-1, w).cpu()
             assert (mine - ref[i][:, 0]).abs().max() <= 5e-6, (B, C, H, W, i)
-        os.environ["NND_CORR_BUILD_V1"] = "1"
-        try:
-            v1 = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
-        finally:
-            del os.environ["NND_CORR_BUILD_V1"]
+        monkeypatch.setenv("NND_CORR_BUILD_V1", "1")
+        v1 = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
+        monkeypatch.delenv("NND_CORR_BUILD_V1")
         assert torch.equal(v1, pyr), (B, C, H, W)
 
 
@@ -366,7 +364,7 @@ def test_refine_wrappers_validate_shapes(raft_sd):
         eng.refine(pyr, 4, 4, net, inp, 8, 1, disp_init=torch.zeros(B, 1, H, W + 1, device=DEV))
 
 
-@pytest.mark.parametrize("arithmetic", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("arithmetic", ["fp32", "bf16x3", "fp16x2"])
 def test_c4_workspace_layout_is_bit_identical_to_planar(raft_sd, monkeypatch, arithmetic):
     """The conv-only workspace tensors (cf, hx, z, rh, ctxb) keep 4 channels interleaved (csrc/layout.h): a pure change of
     addresses — 16-B staging loads and epilogue accesses instead of 4-B ones — so every output must equal the planar

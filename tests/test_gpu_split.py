@@ -1,7 +1,8 @@
-"""GPU: the split-bf16 MFMA convolution (csrc/conv_split.hip, arithmetic "bf16x3") — fp32 operands carried as 3 bf16 pieces,
-6 products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — against float64 truth, against the exact fp32-MFMA kernel,
-and through the whole RAFT-Stereo recurrence against the reference's golden output (north_star bar: <= 1e-4 max-abs).
-The exact fp32 path stays the default; these tests are the gate for selecting the split arithmetic."""
+"""GPU: the split 16-bit MFMA convolutions (csrc/conv_split.hip, csrc/split_arith.h) — arithmetic "bf16x3": fp32 operands carried
+as 3 bf16 pieces, 6 products on v_mfma_f32_32x32x16_bf16; "fp16x2": 2 range-scaled fp16 pieces, 3 products on
+v_mfma_f32_32x32x16_f16; fp32 accumulation in both — against float64 truth, against the exact fp32-MFMA kernel, and through the
+whole RAFT-Stereo recurrence against the reference's golden output (north_star bar: <= 1e-4 max-abs).  These tests (with the
+real-image goldens of test_gpu_realdata.py) are the gate for selecting a split arithmetic."""
 import numpy as np
 import pytest
 import torch
@@ -11,6 +12,7 @@ from conftest import t
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+ARITHS = ["bf16x3", "fp16x2"]  # 3 bf16 pieces / 6 products; 2 range-scaled fp16 pieces / 3 products (csrc/split_arith.h)
 
 # (Cout, Cin, KH, KW, B, H, W): the loop's layers at 68x120 (two-sub-tile workgroups, split-K 2 and 4, 255 = odd number of
 # sub-tiles), ragged images, Cout not a multiple of 32, a 1x1, batch > 1, a single sub-tile
@@ -20,7 +22,8 @@ SHAPES = [(192, 256, 3, 3, 1, 68, 120), (127, 256, 3, 3, 1, 68, 120), (256, 256,
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_split_conv_vs_float64(shape):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_split_conv_vs_float64(shape, arith):
     """Per-op error: |split - fp64 truth| must stay at the level of the exact fp32 kernel's own rounding error."""
     from nndepth_amd import ops
     Cout, Cin, KH, KW, B, H, W = shape
@@ -31,17 +34,20 @@ def test_split_conv_vs_float64(shape):
     truth = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=(KH // 2, KW // 2))
     scale = truth.abs().max().item()
     y32 = ops.Conv2d(w, b)(x.to(DEV)).cpu().double()
-    ysp = ops.Conv2d(w, b, arithmetic="bf16x3")(x.to(DEV)).cpu().double()
+    ysp = ops.Conv2d(w, b, arithmetic=arith)(x.to(DEV)).cpu().double()
     e32, esp = (y32 - truth).abs().max().item(), (ysp - truth).abs().max().item()
     r32, rsp = (y32 - truth).pow(2).mean().sqrt().item(), (ysp - truth).pow(2).mean().sqrt().item()
-    print(f"\n{shape}: max-abs vs fp64  fp32-MFMA {e32:.2e}  bf16x3 {esp:.2e}   rms {r32:.2e} / {rsp:.2e}   (|y| max {scale:.1f})")
-    assert esp <= 2e-5 * max(1.0, scale / 4) and esp <= 3.0 * e32 + 1e-6 and rsp <= 3.0 * r32 + 1e-7
+    print(f"\n{shape}: max-abs vs fp64  fp32-MFMA {e32:.2e}  {arith} {esp:.2e}   rms {r32:.2e} / {rsp:.2e}   (|y| max {scale:.1f})")
+    # the claim of DESIGN.md / bench.py is "per-op error at or below the exact kernel's": max-abs within 25 % of it (a max over
+    # 1e5-1e6 outputs is itself noisy), rms at or below it
+    assert esp <= 2e-5 * max(1.0, scale / 4) and esp <= 1.25 * e32 + 2e-7 * max(1.0, scale) and rsp <= 1.05 * r32 + 2e-8 * max(1.0, scale)
     # ReLU epilogue through the same kernel
-    yr = ops.Conv2d(w, b, arithmetic="bf16x3")(x.to(DEV), relu=True).cpu().double()
+    yr = ops.Conv2d(w, b, arithmetic=arith)(x.to(DEV), relu=True).cpu().double()
     assert (yr - truth.clamp_min(0)).abs().max().item() <= 2e-5 * max(1.0, scale / 4)
 
 
-def test_split_conv_never_reads_outside_the_image():
+@pytest.mark.parametrize("arith", ARITHS)
+def test_split_conv_never_reads_outside_the_image(arith):
     """Same poison-border check as the fp32 kernel's staging (test_conv_staging_never_reads_outside_the_image)."""
     from nndepth_amd import ops
     torch.manual_seed(9)
@@ -52,7 +58,7 @@ def test_split_conv_never_reads_outside_the_image():
         big = torch.full((3, x.numel()), 1e6, device=DEV)
         big[1] = x.reshape(-1).to(DEV)
         ref = torch.nn.functional.conv2d(x, w, b, padding=(KH // 2, KW // 2))
-        y = ops.Conv2d(w, b, arithmetic="bf16x3")(big[1].view(B, Cin, H, W)).cpu()
+        y = ops.Conv2d(w, b, arithmetic=arith)(big[1].view(B, Cin, H, W)).cpu()
         assert (y - ref).abs().max() <= 2e-5, (Cout, Cin, KH, KW, B, H, W, float((y - ref).abs().max()))
 
 
@@ -61,7 +67,8 @@ CASES = {"raft_h128_c64": (128, 64, 36, 1, 8), "raft_h128_c128": (128, 128, 36, 
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_update_block_golden_bf16x3(gold, name):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_update_block_golden_split(gold, name, arith):
     """The reference's update-block outputs (tests/golden/update_block.npz) with every supported conv on the split kernel:
     same tolerance as the exact path."""
     from oracle import torch_ref as R
@@ -70,7 +77,7 @@ def test_update_block_golden_bf16x3(gold, name):
     hid, ctx, cp, fc, sps = CASES[name]
     g = gold("update_block.npz")
     sd = weightgen.fill_state_dict(R.update_block_spec("ub." + name, hid, cp, ctx, fc, sps))
-    ub = BasicUpdateBlock(hidden_dim=hid, cor_planes=cp, context_dim=ctx, flow_channel=fc, spatial_scale=sps, arithmetic="bf16x3")
+    ub = BasicUpdateBlock(hidden_dim=hid, cor_planes=cp, context_dim=ctx, flow_channel=fc, spatial_scale=sps, arithmetic=arith)
     ub.load_state_dict({k[len("ub." + name) + 1:]: v for k, v in sd.items()})
     ub = ub.to(DEV)
     n, m, d = ub(*(t(g[f"{name}_{k}"]).to(DEV) for k in ("net", "inp", "corr", "flow")))
@@ -80,21 +87,22 @@ def test_update_block_golden_bf16x3(gold, name):
         assert err <= 2e-5 * max(1.0, np.abs(exp).max()), (key, err)
 
 
-def test_forward_tartanair_544x960_parity_bf16x3(gold, raft_sd, tartanair_frames):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_forward_tartanair_544x960_parity_split(gold, raft_sd, tartanair_frames, arith):
     """The gate of VERDICT r1 item 5: RAFT-Stereo base, 544x960, 32 iterations, TartanAir pair, loop convs on the split-bf16
     MFMA — max-abs(up_disp - reference forward) <= 1e-4, drift reported at iterations 1 / 4 / 12 / 32, EPE parity."""
     from oracle import torch_ref as R
     from nndepth_amd.cost_volume import CorrBlock1D
     from nndepth_amd.raft_stereo import BaseRAFTStereo
     g = gold("forward_tartanair.npz")
-    m = BaseRAFTStereo(iters=32, context_dim=64, arithmetic="bf16x3")
+    m = BaseRAFTStereo(iters=32, context_dim=64, arithmetic=arith)
     m.load_state_dict(raft_sd, strict=True)
     m = m.to(DEV).eval()
     f1, f2 = tartanair_frames[0].to(DEV), tartanair_frames[1].to(DEV)
     out = m(f1, f2)
     final = out[-1]["up_disp"].cpu()
     err32 = np.abs(final.numpy() - g["up_disp_it32"]).max()
-    print(f"\n[parity bf16x3] tartanair 544x960 it32 max-abs = {err32:.3e}  (|disp| max {np.abs(g['up_disp_it32']).max():.2f})")
+    print(f"\n[parity {arith}] tartanair 544x960 it32 max-abs = {err32:.3e}  (|disp| max {np.abs(g['up_disp_it32']).max():.2f})")
     eng = m.update_block.sync_engine(DEV)
     fmap1, fmap2, cnet = m.forward_fnet(f1, f2)
     net, inp = torch.split(cnet, [128, 64], dim=1)
@@ -103,33 +111,35 @@ def test_forward_tartanair_544x960_parity_bf16x3(gold, raft_sd, tartanair_frames
     for k, it in enumerate(g["low_iters"]):
         _, low, _ = eng.refine(corr._pyr, 4, 4, net, inp, 8, int(it), keep_all=False)
         e = np.abs(low.cpu().numpy() - g["low_disp"][k]).max()
-        print(f"[parity bf16x3] low-res disparity after {int(it):2d} iters: max-abs = {e:.3e}")
+        print(f"[parity {arith}] low-res disparity after {int(it):2d} iters: max-abs = {e:.3e}")
         assert e <= 1e-4
     assert err32 <= 1e-4
     gt = torch.from_numpy(g["gt_disp"].astype(np.float32))
     epe_ref, epe_ours = R.epe(gt, torch.from_numpy(g["up_disp_it32"])), R.epe(gt, final)
-    print(f"[parity bf16x3] EPE ours {epe_ours:.6f} vs reference forward {epe_ref:.6f}")
+    print(f"[parity {arith}] EPE ours {epe_ours:.6f} vs reference forward {epe_ref:.6f}")
     assert abs(epe_ours - epe_ref) <= 1e-4
 
 
-def test_forward_small_golden_bf16x3(gold, raft_sd):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_forward_small_golden_split(gold, raft_sd, arith):
     from nndepth_amd import weightgen
     from nndepth_amd.raft_stereo import BaseRAFTStereo
     g = gold("forward_small.npz")
     f1, f2 = weightgen.synthetic_frames(0, 1, 96, 160)
-    m = BaseRAFTStereo(iters=6, context_dim=64, arithmetic="bf16x3")
+    m = BaseRAFTStereo(iters=6, context_dim=64, arithmetic=arith)
     m.load_state_dict(raft_sd, strict=True)
     out = m.to(DEV).eval()(f1.to(DEV), f2.to(DEV))
     for i in range(6):
         assert np.abs(out[i]["up_disp"].cpu().numpy() - g["up_disp"][i]).max() <= 1e-4, i
 
 
-def test_encoder_fullsize_bf16x3_vs_oracle(raft_sd, tartanair_frames):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_encoder_fullsize_split_vs_oracle(raft_sd, tartanair_frames, arith):
     """f-1 with arithmetic bf16x3: the encoder's stride-1 3x3 convolutions and cnet_proj on the split kernel (stem, stride-2
     and 1x1 layers exact fp32) at 544x960 against the oracle's encoder: same bound as the exact path (<= 5e-5)."""
     from oracle import torch_ref as R
     from nndepth_amd.raft_stereo import BaseRAFTStereo
-    m = BaseRAFTStereo(iters=1, context_dim=64, arithmetic="bf16x3")
+    m = BaseRAFTStereo(iters=1, context_dim=64, arithmetic=arith)
     m.load_state_dict(raft_sd, strict=True)
     m = m.to(DEV).eval()
     f1, f2 = tartanair_frames
@@ -139,26 +149,28 @@ def test_encoder_fullsize_bf16x3_vs_oracle(raft_sd, tartanair_frames):
         ref_c = torch.relu(R._conv(raft_sd, "cnet_proj.0", ref[:1], padding=1))
     e1 = (torch.cat([fm1, fm2]).cpu() - ref).abs().max().item()
     e2 = (cnet.cpu() - ref_c).abs().max().item()
-    print(f"\nencoder bf16x3 544x960: fmap max-abs {e1:.2e} (|fmap| max {ref.abs().max():.2f}), cnet {e2:.2e}")
+    print(f"\nencoder {arith} 544x960: fmap max-abs {e1:.2e} (|fmap| max {ref.abs().max():.2f}), cnet {e2:.2e}")
     assert e1 <= 5e-5 and e2 <= 5e-5
 
 
-def test_cre_cascade_small_golden_bf16x3(gold, cre_sd):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_cre_cascade_small_golden_split(gold, cre_sd, arith):
     """a20 with the split arithmetic: the reference's 8 cascade outputs (tests/golden/cre_forward.npz), instance-norm encoder
     and update block on the split kernel."""
     from nndepth_amd import weightgen
     from nndepth_amd.cre_stereo import CREStereoBase
     g = gold("cre_forward.npz")
     fr1, fr2 = weightgen.synthetic_frames(3, 1, 128, 192)
-    m = CREStereoBase(iters=4, arithmetic="bf16x3")
+    m = CREStereoBase(iters=4, arithmetic=arith)
     m.load_state_dict(cre_sd, strict=True)
     outs = m.to(DEV).eval()(fr1.to(DEV), fr2.to(DEV))
     errs = [np.abs(o["up_disp"].cpu().numpy() - g[f"up_disp_{i}"]).max() for i, o in enumerate(outs)]
-    print("\ncre cascade bf16x3 max-abs per output:", " ".join(f"{e:.2e}" for e in errs))
+    print(f"\ncre cascade {arith} max-abs per output:", " ".join(f"{e:.2e}" for e in errs))
     assert len(outs) == 8 and max(errs) <= 1e-4
 
 
-def test_igev_forward_golden_bf16x3(gold):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_igev_forward_golden_split(gold, arith):
     """a16 with the split arithmetic in the loop: the reference's IGEVStereoBase outputs on the tiny backbone."""
     import os
     import sys
@@ -167,18 +179,19 @@ def test_igev_forward_golden_bf16x3(gold):
     from nndepth_amd import weightgen
     from nndepth_amd.igev_stereo import IGEVStereoBase, CostVolumeFilterNetwork
     g = gold("igev_forward.npz")
-    m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=4, hidden_dim=64, context_dim=64, arithmetic="bf16x3")
+    m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=4, hidden_dim=64, context_dim=64, arithmetic=arith)
     weightgen.fill_module_(m, "igev.")
     m = m.to(DEV).eval()
     f1, f2 = weightgen.synthetic_frames(6, 1, 128, 192)
     outs = m(f1.to(DEV), f2.to(DEV))
     errs = [np.abs(o["up_disp"].cpu().numpy() - g["up_disp"][i]).max() for i, o in enumerate(outs)]
-    print("\nigev forward bf16x3 max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
+    print(f"\nigev forward {arith} max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
     assert len(outs) == 4 and max(errs) <= 1e-4
 
 
 @pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
-def test_igev_regulariser_golden_bf16x3(gold, name, B, H, W):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_igev_regulariser_golden_split(gold, name, B, H, W, arith):
     """a15 with the stride-1 Conv3d layers on the split kernel: the reference's regularised volume (igev_volume.npz: geo0)."""
     from nndepth_amd import weightgen
     from nndepth_amd.cost_volume import GeometryAwareCostVolume
@@ -189,16 +202,17 @@ def test_igev_regulariser_golden_bf16x3(gold, name, B, H, W):
                                                    ).reshape(B, c, H >> (j + 1), W >> (j + 1))).to(DEV)
               for j, c in enumerate((40, 80, 160))]
     reg = CostVolumeFilterNetwork(8, [40, 80, 160]).eval()
-    reg.arithmetic = "bf16x3"
+    reg.arithmetic = arith
     weightgen.fill_module_(reg, "igev.cv_regularizer.")
     cv = GeometryAwareCostVolume(f1, f2, guides, reg.to(DEV), 4, 4, 8)
     err = np.abs(cv.geo_aware_cv[0][:, 0].cpu().numpy() - g[name + "_geo0"]).max()
-    print(f"\nregulariser bf16x3 {name}: vs reference {err:.2e}")
+    print(f"\nregulariser {arith} {name}: vs reference {err:.2e}")
     assert err <= 2e-5
 
 
 @pytest.mark.parametrize("fc", [1, 2])
-def test_fused_mask_upsample_bf16x3_matches_unfused(raft_sd, monkeypatch, fc):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_fused_mask_upsample_split_matches_unfused(raft_sd, monkeypatch, fc, arith):
     """bf16x3: mask.2 runs inside the fused mask + softmax + upsample kernel on the bf16 MFMA with split operands
     (mask_upsample_kernel<.., SPLIT>: x tile split while it is staged, weights in conv_split's packing).  Against the
     unfused pair of launches (NND_NO_FUSED_UPSAMPLE: conv_split 1x1 -> mask in HBM -> convex_upsample): same arithmetic,
@@ -208,7 +222,7 @@ def test_fused_mask_upsample_bf16x3_matches_unfused(raft_sd, monkeypatch, fc):
     from nndepth_amd.ops import UpdateBlockEngine  # noqa: F401
 
     def run():
-        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=fc, spatial_scale=8, arithmetic="bf16x3")
+        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=fc, spatial_scale=8, arithmetic=arith)
         weightgen.fill_module_(ub, "update_block.")
         ub = ub.to(DEV).eval()
         eng = ub.sync_engine(DEV)
@@ -233,7 +247,8 @@ def test_fused_mask_upsample_bf16x3_matches_unfused(raft_sd, monkeypatch, fc):
 
 
 @pytest.mark.parametrize("fc", [1, 2])
-def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc, arith):
     """bf16x3: the motion encoder's flow branch is ONE launch (conv_split.hip: flow_branch_kernel) — convf1's 7x7 on the VALU
     from an LDS copy of the flow window in convf1_kernel's tap order, its output split into bf16 pieces straight into convf2's
     LDS patch, then conv_split's MFMA walk with 4 K slices.  With every conv forced to ks = 4
@@ -244,7 +259,7 @@ def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc):
     from nndepth_amd.blocks import BasicUpdateBlock
 
     def run():
-        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=fc, spatial_scale=8, arithmetic="bf16x3")
+        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=fc, spatial_scale=8, arithmetic=arith)
         weightgen.fill_module_(ub, "update_block.")
         ub = ub.to(DEV).eval()
         torch.manual_seed(21)
