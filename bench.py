@@ -10,10 +10,11 @@ with the RCCL all-gather of the final disparity.  Inputs are resident in HBM bef
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  "roofline":     dominant kernel (fp32-MFMA implicit-GEMM conv) measured live with hipEvents on the
-                  launch stream, against the 157.3 TFLOP/s fp32 MFMA peak: `achieved` is its duration INSIDE the
-                  fused loop (nnd_profile_loop_conv), `standalone` the same launch alone on the chip
-                  (nnd_profile_conv); `hbm_group` = the HBM-bound kernels of the path (pyramid build, lookup,
+  "roofline":     dominant kernel (the implicit-GEMM conv of encoder.convc2 in the selected arithmetic) measured live
+                  with hipEvents on the launch stream: `achieved` = algorithmic TFLOP/s from its duration INSIDE the
+                  fused loop (nnd_profile_loop_conv), `peak` = dense 16-bit MFMA peak (2500 TFLOP/s) / MFMA products per fp32
+                  product of the arithmetic (157.3 for the exact fp32 MFMA), `standalone` the same launch alone on the
+                  chip (nnd_profile_conv); `hbm_group` = the HBM-bound kernels of the path (pyramid build, lookup,
                   upsample, IGEV / CREStereo volume kernels) against the 8 TB/s roofline, same run;
   "cpu_baseline": the oracle's PyTorch-eager CPU restatement of the reference forward timed on the
                   host cores (rank 0, N=1 only), and the GPU-vs-oracle max-abs of that same pair.
@@ -77,10 +78,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hbm-group", action="store_true")
-    ap.add_argument("--arithmetic", default="bf16x3", choices=["bf16x3", "fp16x2", "fp32"],
-                    help="MFMA arithmetic of the update-block convolutions: bf16x3 = fp32 operands carried as 3 bf16 pieces, 6 "
-                         "products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/conv_split.hip; parity-gated, default); "
-                         "fp32 = exact fp32 MFMA (csrc/conv_mfma.hip)")
+    ap.add_argument("--arithmetic", default="fp16x2", choices=["fp16x2", "bf16x3", "fp32"],
+                    help="MFMA arithmetic of the update-block / encoder convolutions (the model classes' default is the same): fp16x2 = "
+                         "fp32 operands carried as 2 range-scaled fp16 pieces, 3 products on v_mfma_f32_32x32x16_f16; bf16x3 = 3 bf16 "
+                         "pieces, 6 products on v_mfma_f32_32x32x16_bf16; fp32 accumulate in both (csrc/conv_split.hip, parity-gated by "
+                         "tests/test_gpu_split.py + tests/test_gpu_realdata.py); fp32 = exact fp32 MFMA (csrc/conv_mfma.hip)")
     ap.add_argument("--config", default="raft544", choices=["raft544", "kitti64", "cre8"],
                     help="raft544 = BASELINE.json configs[1] (the headline, default); kitti64 = configs[3]: 64 KITTI-size pairs "
                          "sharded over the ranks; cre8 = configs[4]: 8 CREStereo 1080x1920 pairs, 2-stage cascade, sharded")
@@ -175,6 +177,7 @@ def main():
             ex_out = exact(f1, f2)
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t1) / n_ex
+        result["exact_fp32_pairs_per_s"] = 1.0 / dt  # the same pair through the exact fp32-MFMA path, same run
         result["exact_fp32_path"] = {
             "value": 1.0 / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": n_ex, "dtype": DTYPE["fp32"],
             "max_abs_up_disp_vs_this_run": float((ex_out[-1]["up_disp"] - out[-1]["up_disp"]).abs().max())}
@@ -212,21 +215,24 @@ def main():
             loop_ms += r["ms_in_loop"]
             loop_fl += r["gflop"]
         nprod = SPLIT_PRODUCTS[args.arithmetic]  # MFMA FLOPs executed per algorithmic FLOP
-        peak = PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS
+        # `achieved` / `peak` are ALGORITHMIC TFLOP/s: peak = what the matrix pipe could deliver of this arithmetic's fp32-equivalent
+        # products = dense 16-bit MFMA peak / products per fp32 product (fp16x2: 2500 / 3 = 833; bf16x3: 2500 / 6 = 417; fp32: 157.3).
+        # frac is therefore also the executed-MFMA utilisation (executed = nprod x algorithmic, against 2500).
+        peak = PEAK_FP32_MFMA_TFLOPS if nprod == 1 else PEAK_BF16_MFMA_TFLOPS / nprod
         kern = {1: "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                 6: "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 6 products per fp32 product)",
                 3: "conv_split_kernel (v_mfma_f32_32x32x16_f16, 3 products per fp32 product)"}[nprod]
         result["roofline"] = {
             "bound": "mfma", "kernel": kern + " — " + dom["conv"],
-            "achieved": nprod * dom["tflops_in_loop"], "peak": peak, "unit": "TFLOP/s",
-            "frac": nprod * dom["tflops_in_loop"] / peak, "traffic": _traffic(args.arithmetic),
-            "flops_counted": "MFMA FLOPs executed = %d x algorithmic (2*B*H*W*Cout*Cin*KH*KW)" % nprod,
-            "algorithmic_tflops": dom["tflops_in_loop"],
+            "achieved": dom["tflops_in_loop"], "peak": peak, "unit": "TFLOP/s",
+            "frac": dom["tflops_in_loop"] / peak, "traffic": _traffic(args.arithmetic),
+            "flops_counted": "algorithmic (2*B*H*W*Cout*Cin*KH*KW); peak = dense 16-bit MFMA peak 2500 TFLOP/s / %d MFMA products per "
+                             "fp32 product" % nprod if nprod > 1 else "algorithmic (2*B*H*W*Cout*Cin*KH*KW) against the fp32 MFMA peak",
+            "executed_mfma_tflops": nprod * dom["tflops_in_loop"], "executed_mfma_peak": PEAK_BF16_MFMA_TFLOPS if nprod > 1 else PEAK_FP32_MFMA_TFLOPS,
             "algorithmic_frac_of_fp32_mfma_peak": dom["tflops_in_loop"] / PEAK_FP32_MFMA_TFLOPS,
             "measured": "inside the fused 32-iteration loop (hipEvents around the launch on its stream, average of iterations 2..32)",
             "launch_ms": dom["ms_in_loop"], "launch_gflop": dom["gflop"],
-            "standalone": {"launch_ms": dom["ms"], "algorithmic_tflops": dom["tflops"], "achieved": nprod * dom["tflops"],
-                           "frac": nprod * dom["tflops"] / peak},
+            "standalone": {"launch_ms": dom["ms"], "achieved": dom["tflops"], "frac": dom["tflops"] / peak},
             # aggregates in ALGORITHMIC TFLOP/s, as a fraction of the exact-fp32 MFMA ceiling the path used to sit under
             "all_convs": {"ms_per_iter": tot_ms, "gflop_per_iter": tot_fl / 1e9,
                           "tflops": tot_fl / tot_ms / 1e9, "frac": tot_fl / tot_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,

@@ -122,9 +122,9 @@ class CREStereoBase(nn.Module):
                  max_disp: int = 192, num_fnet_channels: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  search_num: int = 9, mixed_precision: bool = False, test_mode: bool = False, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, hip_encoder: bool = True, arithmetic: str = "fp32", **kwargs):
+                 fused_loop: bool = True, hip_encoder: bool = True, arithmetic: str = "fp16x2", **kwargs):
         super().__init__()
-        self.arithmetic = arithmetic  # update-block convolutions: "fp32" (exact) or "bf16x3" (split bf16 MFMA)
+        self.arithmetic = arithmetic  # update-block / encoder convolutions: "fp16x2" (default; 2 fp16 pieces, parity-gated), "bf16x3" (3 bf16 pieces) or "fp32" (exact fp32 MFMA)
         if fnet_cls != "basic_encoder" or update_cls != "basic_update_block":
             raise ValueError("CREStereoBase: only basic_encoder / basic_update_block exist (as in the reference)")
         if context_dim != hidden_dim:

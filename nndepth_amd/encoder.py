@@ -1,9 +1,10 @@
 """Feature encoder used by RAFT-Stereo (reference: nndepth/encoders/basic_encoder.py:8-93,
 nndepth/blocks/residual_block.py:6-60).
 
-NOT part of the replaced hot path: SURVEY.md §8f-1 ranks the encoder as the next row to move to
-hand-written MFMA kernels.  Until then it runs on PyTorch-ROCm (MIOpen) so that `forward()` is
-end-to-end; module / parameter names match the reference so its checkpoints load unchanged.
+Parameter container for SURVEY.md §8f-1: module / parameter names match the reference so its checkpoints load unchanged.
+At inference the model classes run the encoder as hand-written HIP (csrc/encoder.hip through ops.EncoderEngine, one C-ABI call:
+nnd_encoder_forward) straight from these parameters; this module's own `forward` is the plain PyTorch-ROCm formulation and is
+only reached through the explicit opt-out `hip_encoder=False` of the model classes (never silently).
 """
 import torch
 import torch.nn as nn

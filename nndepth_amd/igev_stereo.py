@@ -160,9 +160,9 @@ class IGEVStereoBase(nn.Module):
     def __init__(self, update_cls: str = "basic_update_block", cv_groups: int = 8, iters: int = 12, hidden_dim: int = 128,
                  context_dim: int = 128, corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, arithmetic: str = "fp32"):
+                 fused_loop: bool = True, arithmetic: str = "fp16x2"):
         super().__init__()
-        self.arithmetic = arithmetic  # update-block convolutions: "fp32" (exact) or "bf16x3" (split bf16 MFMA)
+        self.arithmetic = arithmetic  # update-block / encoder convolutions: "fp16x2" (default; 2 fp16 pieces, parity-gated), "bf16x3" (3 bf16 pieces) or "fp32" (exact fp32 MFMA)
         if update_cls != "basic_update_block":
             raise KeyError(update_cls)
         self.fnet = self._init_fnet()
@@ -236,9 +236,10 @@ class IGEVStereoBase(nn.Module):
             init = ops.softargmin_disparity(logits.float())
         if self.fused_loop and isinstance(corr, GeometryAwareCostVolume):
             eng = self.update_block.sync_engine(frame1.device)
-            up, _, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,
-                                       net.float(), inp.float(), fnet_ds, self.iters, disp_init=init, keep_all=True,
-                                       interleaved=corr.interleaved())
+            up, low, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,
+                                         net.float(), inp.float(), fnet_ds, self.iters, disp_init=init, keep_all=True,
+                                         interleaved=corr.interleaved())
+            self.last_low_coords = low  # the loop's state after the last iteration: absolute coordinates at 1/4 resolution (Q5)
             return [{"up_disp": up[i]} for i in range(self.iters)]
         coords1 = self.initialize_coords(fmap1) + init
         outs = []
@@ -246,6 +247,7 @@ class IGEVStereoBase(nn.Module):
             net, mask, delta = self.update_block(net, inp, corr(coords1), coords1)
             coords1 = coords1 + delta
             outs.append({"up_disp": self.convex_upsample(coords1, mask, rate=fnet_ds)})
+        self.last_low_coords = coords1
         return outs
 
 

@@ -65,9 +65,9 @@ class BaseRAFTStereo(nn.Module):
     def __init__(self, iters: int = 12, fnet_dim: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
-                 fused_loop: bool = True, hip_encoder: bool = True, arithmetic: str = "fp32", **kwargs):
+                 fused_loop: bool = True, hip_encoder: bool = True, arithmetic: str = "fp16x2", **kwargs):
         super().__init__()
-        self.arithmetic = arithmetic  # convolutions of the fused loop: "fp32" (exact) or "bf16x3" (split bf16 MFMA)
+        self.arithmetic = arithmetic  # update-block / encoder convolutions: "fp16x2" (default; 2 fp16 pieces, parity-gated), "bf16x3" (3 bf16 pieces) or "fp32" (exact fp32 MFMA)
         self.iters, self.fnet_dim, self.hidden_dim, self.context_dim = iters, fnet_dim, hidden_dim, context_dim
         self.corr_levels, self.corr_radius = corr_levels, corr_radius
         self.tracing, self.include_preprocessing = tracing, include_preprocessing
@@ -147,9 +147,9 @@ class BaseRAFTStereo(nn.Module):
 STEREO_MODELS = {"base-raft-stereo": BaseRAFTStereo}
 
 
-def patch(model: nn.Module) -> nn.Module:
+def patch(model: nn.Module, arithmetic: str = "fp16x2") -> nn.Module:
     """Swap the HIP hot path into a reference-style RAFT-Stereo instance in place:
-    `corr_fn`, `update_block` (state_dict carried over) and `convex_upsample`."""
+    `corr_fn`, `update_block` (state_dict carried over) and `convex_upsample`.  `arithmetic`: as on the model classes."""
     old = model.update_block
     sd = old.state_dict()
     hid = sd["flow_head.conv1.weight"].shape[0]
@@ -158,7 +158,7 @@ def patch(model: nn.Module) -> nn.Module:
                            context_dim=gin - 2 * hid,
                            gru="sep_conv" if "gru.convz2.weight" in sd else "conv_gru",
                            flow_channel=sd["flow_head.conv2.weight"].shape[0],
-                           spatial_scale=int(round((sd["mask.2.weight"].shape[0] // 9) ** 0.5)))
+                           spatial_scale=int(round((sd["mask.2.weight"].shape[0] // 9) ** 0.5)), arithmetic=arithmetic)
     new.load_state_dict(sd, strict=True)
     new.to(next(old.parameters()).device)
     model.update_block = new

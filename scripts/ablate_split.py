@@ -14,7 +14,7 @@ from nndepth_amd import weightgen
 from nndepth_amd.blocks import BasicUpdateBlock
 from nndepth_amd._lib import LIB_PATH
 H, W = int(os.environ.get("AB_H", 68)), int(os.environ.get("AB_W", 120))
-ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic="bf16x3")
+ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic=os.environ.get("AB_ARITH", "fp16x2"))
 weightgen.fill_module_(ub, "update_block.")
 ub = ub.to("cuda:0"); eng = ub.sync_engine("cuda:0")
 ws = eng.workspace(1, H, W, "cuda:0"); ws.normal_()

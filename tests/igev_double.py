@@ -46,3 +46,4 @@ def make_igev(base_cls, regulariser_cls, **kwargs):
             return fmap1, fmap2, cnet1, [f[:B] for f in feats[1:]]
 
     return TinyIGEV(**kwargs)
+

@@ -194,14 +194,16 @@ def test_update_block_fullsize_vs_oracle(R):
         assert err <= 2e-5 * max(1.0, b.abs().max().item()), f"{nm}: {err}"
 
 
-def test_update_block_conv_gru_vs_oracle(R, ops):
+@pytest.mark.parametrize("arithmetic", ["fp32", "bf16x3", "fp16x2"])
+def test_update_block_conv_gru_vs_oracle(R, ops, arithmetic):
     """Row a7: the single 3x3 ConvGRU variant (gru="conv_gru", nndepth/blocks/gru.py:53-61; Coarse2Fine's update block):
     one application of the block, then the fused loop (lookup -> block -> coords += delta -> upsample) for 3 iterations
-    against the same loop composed from the oracle's pieces."""
+    against the same loop composed from the oracle's pieces — in the exact and in both split arithmetics."""
     from nndepth_amd import weightgen
     from nndepth_amd.blocks import BasicUpdateBlock
     sd = weightgen.fill_state_dict(R.update_block_spec("update_block", 128, 36, 128, 1, 8, gru="conv_gru"))
-    ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=128, flow_channel=1, spatial_scale=8, gru="conv_gru")
+    ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=128, flow_channel=1, spatial_scale=8, gru="conv_gru",
+                          arithmetic=arithmetic)
     ub.load_state_dict({k[len("update_block."):]: v for k, v in sd.items()})
     ub = ub.to(DEV)
     torch.manual_seed(31)

@@ -1,0 +1,111 @@
+"""GPU: real-image parity against the imported reference (goldens of oracle/make_golden_realdata.py), in the exact and in both
+split arithmetics — the wider gate that licenses a split arithmetic as the default of the model classes:
+
+  KITTI sample pair 375x1242 -> Padder(32) -> RAFT-Stereo base, 32 iterations          (BASELINE.json configs[3], per pair)
+  TartanAir sample pair 544x960 -> CREStereo, iters = 4 (8 outputs of the 3-scale cascade)
+  TartanAir sample pair 544x960 -> IGEV on the tiny backbone, 32 iterations            (configs[2], per sample)
+
+Bar: <= 1e-4 max-abs on the final full-resolution map (north_star), drift printed at iterations 1 / 4 / 12 / 32.  IGEV's
+full-resolution output is 4 x the ABSOLUTE coordinate (reference quirk Q5: values up to ~530, one fp32 ulp = 6.1e-5) and the
+reference's own 1-thread vs 8-thread runs differ by 1.8e-4 there, so that one map is held to 2 x the reference's stored
+self-noise while the 1/4-resolution coordinates themselves are held to 1e-4."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ARITHS = ["fp32", "bf16x3", "fp16x2"]
+
+
+def _png(name):
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(GOLD, name)).convert("RGB"))
+    return torch.from_numpy(img.copy()).permute(2, 0, 1).float().unsqueeze(0)
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_raft_kitti_pair_32_iterations_vs_reference(gold, raft_sd, arith):
+    from nndepth_amd.cost_volume import CorrBlock1D
+    from nndepth_amd.prepost import Padder
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+    g = gold("forward_kitti.npz")
+    frames = [((_png(f"kitti_000000_10_{s}.png") - 127.5) / 127.5).to(DEV) for s in ("left", "right")]
+    padder = Padder((375, 1242), divis_by=32)
+    p1, p2 = padder.pad(*frames)
+    assert tuple(p1.shape) == (1, 3, 384, 1248) and list(g["pad"]) == list(padder._pad)
+    m = BaseRAFTStereo(iters=32, context_dim=64, arithmetic=arith)
+    m.load_state_dict(raft_sd, strict=True)
+    m = m.to(DEV).eval()
+    out = m(p1, p2)
+    final = out[-1]["up_disp"].cpu().numpy()
+    err32 = np.abs(final - g["up_disp_it32"]).max()
+    print(f"\n[kitti {arith}] 384x1248 it32 max-abs vs reference = {err32:.3e}  (|disp| max {np.abs(g['up_disp_it32']).max():.2f})")
+    eng = m.update_block.sync_engine(DEV)
+    fmap1, fmap2, cnet = m.forward_fnet(p1, p2)
+    net, inp = torch.split(cnet, [128, 64], dim=1)
+    net, inp = torch.tanh(net), torch.relu(inp)
+    corr = CorrBlock1D(fmap1, fmap2, 4, 4)
+    for k, it in enumerate(g["low_iters"]):
+        _, low, _ = eng.refine(corr._pyr, 4, 4, net, inp, 8, int(it), keep_all=False)
+        e = np.abs(low.cpu().numpy() - g["low_disp"][k]).max()
+        print(f"[kitti {arith}] low-res disparity after {int(it):2d} iters: max-abs = {e:.3e}")
+        assert e <= 1e-4
+    assert err32 <= 1e-4
+    # EPE parity on the sample's ground truth (valid pixels), through the device-side unpad
+    valid = np.unpackbits(g["gt_valid"])[:375 * 1242].reshape(375, 1242).astype(bool)
+    ours = padder.unpad(out[-1]["up_disp"])[0, 0].cpu().numpy()
+    epe = float(np.abs(ours - g["gt_disp"].astype(np.float32))[valid].mean())
+    print(f"[kitti {arith}] EPE ours {epe:.6f} vs reference forward {float(g['epe_ref']):.6f}")
+    assert abs(epe - float(g["epe_ref"])) <= 1e-4
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_cre_tartanair_544x960_vs_reference(gold, cre_sd, tartanair_frames, arith):
+    from nndepth_amd.cre_stereo import CREStereoBase
+    g = gold("forward_cre_tartanair.npz")
+    m = CREStereoBase(iters=4, arithmetic=arith)
+    m.load_state_dict(cre_sd, strict=True)
+    outs = m.to(DEV).eval()(tartanair_frames[0].to(DEV), tartanair_frames[1].to(DEV))
+    assert len(outs) == 8
+    errs = [np.abs(o["up_disp"].cpu().numpy()[:, :, ::4, ::4] - g[f"up_disp_sub4_{i}"]).max() for i, o in enumerate(outs[:-1])]
+    errs.append(np.abs(outs[-1]["up_disp"].cpu().numpy() - g["up_disp_final"]).max())
+    print(f"\n[cre {arith}] 544x960 iters=4 max-abs per output: " + " ".join(f"{e:.2e}" for e in errs) +
+          f"  (|flow| max {np.abs(g['up_disp_final']).max():.1f})")
+    assert max(errs) <= 1e-4
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_igev_tartanair_544x960_32_iterations_vs_reference(gold, tartanair_frames, arith):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from igev_double import make_igev
+    from nndepth_amd import weightgen
+    from nndepth_amd.igev_stereo import IGEVStereoBase, CostVolumeFilterNetwork
+    g = gold("forward_igev_tartanair.npz")
+    m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=32, hidden_dim=64, context_dim=64, arithmetic=arith)
+    weightgen.fill_module_(m, "igev.")
+    m = m.to(DEV).eval()
+    f1, f2 = tartanair_frames[0].to(DEV), tartanair_frames[1].to(DEV)
+    outs = m(f1, f2)
+    final = outs[-1]["up_disp"].cpu().numpy()
+    err_up = np.abs(final - g["up_disp_it32"]).max()
+    tol_up = max(1e-4, 2.0 * float(g["ref_self_noise_up"].max()))
+    print(f"\n[igev {arith}] 544x960 it32 up_disp max-abs vs reference = {err_up:.3e}  (|4 x coords| max {np.abs(g['up_disp_it32']).max():.1f}, "
+          f"reference self-noise {float(g['ref_self_noise_up'].max()):.2e}, tolerance {tol_up:.2e})")
+    # the 1/4-resolution coordinates after 1 / 4 / 12 / 32 iterations: every 4th pixel of up_disp is NOT the coordinate (convex
+    # combination), so re-run with fewer iterations and read the loop's own low-resolution state
+    for k, it in enumerate(g["low_iters"]):
+        mk = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=int(it), hidden_dim=64, context_dim=64, arithmetic=arith)
+        mk.load_state_dict(m.state_dict())
+        mk = mk.to(DEV).eval()
+        mk(f1, f2)
+        low = mk.last_low_coords.cpu().numpy()
+        e = np.abs(low - g["low_coords"][k]).max()
+        print(f"[igev {arith}] 1/4-resolution coordinates after {int(it):2d} iters: max-abs = {e:.3e}  (reference self-noise {float(g['ref_self_noise_low'][k]):.2e})")
+        assert e <= 1e-4
+    assert err_up <= tol_up

@@ -87,6 +87,30 @@ def test_update_block_golden_split(gold, name, arith):
         assert err <= 2e-5 * max(1.0, np.abs(exp).max()), (key, err)
 
 
+GRU_CASES = {"convgru_h128_c128": (128, 128, 36, 1, 8), "convgru_h64_c64_f2": (64, 64, 36, 2, 4)}
+
+
+@pytest.mark.parametrize("name", list(GRU_CASES))
+@pytest.mark.parametrize("arith", ARITHS)
+def test_update_block_conv_gru_golden_split(gold, name, arith):
+    """Row a7 in the split arithmetics: the reference's BasicUpdateBlock(gru="conv_gru") outputs
+    (tests/golden/update_block_conv_gru.npz, nndepth/blocks/gru.py:53-61), same tolerance as the exact path."""
+    from oracle import torch_ref as R
+    from nndepth_amd import weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    hid, ctx, cp, fc, sps = GRU_CASES[name]
+    g = gold("update_block_conv_gru.npz")
+    sd = weightgen.fill_state_dict(R.update_block_spec("ub." + name, hid, cp, ctx, fc, sps, gru="conv_gru"))
+    ub = BasicUpdateBlock(hidden_dim=hid, cor_planes=cp, context_dim=ctx, flow_channel=fc, spatial_scale=sps, gru="conv_gru", arithmetic=arith)
+    ub.load_state_dict({k[len("ub." + name) + 1:]: v for k, v in sd.items()})
+    ub = ub.to(DEV)
+    n, m, d = ub(*(t(g[f"{name}_{k}"]).to(DEV) for k in ("net", "inp", "corr", "flow")))
+    for got, key in ((n, "net_out"), (m, "mask_out"), (d, "delta_out")):
+        exp = g[f"{name}_{key}"]
+        err = np.abs(got.cpu().numpy() - exp).max()
+        assert err <= 2e-5 * max(1.0, np.abs(exp).max()), (key, err)
+
+
 @pytest.mark.parametrize("arith", ARITHS)
 def test_forward_tartanair_544x960_parity_split(gold, raft_sd, tartanair_frames, arith):
     """The gate of VERDICT r1 item 5: RAFT-Stereo base, 544x960, 32 iterations, TartanAir pair, loop convs on the split-bf16

@@ -66,3 +66,15 @@ def test_cre_model_state_dict_matches_spec(cre_sd):
     m.load_state_dict(cre_sd, strict=True)
     with pytest.raises(ValueError):
         CREStereoBase(hidden_dim=128, context_dim=64)
+
+
+def test_cascade_tartanair_544x960_realdata(gold, cre_sd, tartanair_frames):
+    """oracle/make_golden_realdata.py cre: the oracle's cascade on the TartanAir sample pair at 544x960, iters = 4, against the
+    imported reference's 8 outputs (<= 4.8e-6 at generation time, tests/golden/REPORT_realdata.txt)."""
+    g = gold("forward_cre_tartanair.npz")
+    with torch.no_grad():
+        outs = C.cre_stereo_forward(cre_sd, tartanair_frames[0], tartanair_frames[1], 4)
+    assert len(outs) == 8
+    for i, o in enumerate(outs[:-1]):
+        assert np.abs(o.numpy()[:, :, ::4, ::4] - g[f"up_disp_sub4_{i}"]).max() <= 2e-5, i
+    assert np.abs(outs[-1].numpy() - g["up_disp_final"]).max() <= 2e-5

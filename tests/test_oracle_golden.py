@@ -160,3 +160,24 @@ def test_igev_regulariser_oracle(gold, name, B, H, W):
         geo = R.cost_volume_filter(sd, "igev.cv_regularizer", fvol.permute(0, 1, 4, 2, 3), guides)
     got = geo.permute(0, 1, 3, 4, 2).reshape(-1, W).numpy()
     assert np.abs(got - g[name + "_geo0"]).max() <= 2e-6
+
+
+def test_raft_kitti_realdata_oracle(gold, raft_sd):
+    """oracle/make_golden_realdata.py kitti: the oracle's RAFT-Stereo forward on the reference's KITTI sample pair
+    (375x1242 -> Padder(32) -> 384x1248, 32 iterations) against the imported reference's output.  The same code gave 0.0 at
+    generation time (tests/golden/REPORT_realdata.txt); across thread counts the reference itself moves by ~3e-5."""
+    import os
+    from PIL import Image
+    g = gold("forward_kitti.npz")
+    frames = []
+    for side in ("left", "right"):
+        img = np.asarray(Image.open(os.path.join(os.path.dirname(__file__), "golden", f"kitti_000000_10_{side}.png")).convert("RGB"))
+        frames.append((torch.from_numpy(img.copy()).permute(2, 0, 1).float().unsqueeze(0) - 127.5) / 127.5)
+    pads = R.padder_pads((375, 1242), 32)
+    assert pads == list(g["pad"])
+    p1, p2 = R.padder_pad(frames[0], pads), R.padder_pad(frames[1], pads)
+    with torch.no_grad():
+        ups, lows = R.raft_stereo_forward(raft_sd, p1, p2, 32, return_lowres=True)
+    assert np.abs(ups[-1].numpy() - g["up_disp_it32"]).max() <= 1e-4
+    for k, it in enumerate(g["low_iters"]):
+        assert np.abs(lows[int(it) - 1].numpy() - g["low_disp"][k]).max() <= 1e-4, it
