@@ -210,18 +210,20 @@ def raft_stereo_forward(sd: SD, frame1: torch.Tensor, frame2: torch.Tensor, iter
     return (ups, lows) if return_lowres else ups
 
 
-def igev_refine(sd: SD, p: str, fp, gp, net, inp, init_disp, iters: int, num_groups=8, num_levels=4, radius=4, rate=4):
+def igev_refine(sd: SD, p: str, fp, gp, net, inp, init_disp, iters: int, num_groups=8, num_levels=4, radius=4, rate=4,
+                return_lowres: bool = False):
     """nndepth/models/igev_stereo/model.py:148-158: coords1 = arange + init; the update block and the upsample take the
-    ABSOLUTE coords1 (Q5).  -> list of up (B,1,rate*H,rate*W)."""
+    ABSOLUTE coords1 (Q5).  -> list of up (B,1,rate*H,rate*W) [, list of the low-resolution coords1 after each iteration]."""
     B, _, H, W = net.shape
     coords1 = torch.arange(W).float()[None, None, None, :].repeat(B, 1, H, 1) + init_disp
-    ups = []
+    ups, lows = [], []
     for _ in range(iters):
         samp = igev_lookup(fp, gp, coords1, num_groups, num_levels, radius)
         net, mask, delta = update_block(sd, p, net, inp, samp, coords1)
         coords1 = coords1 + delta
+        lows.append(coords1)
         ups.append(convex_upsample(coords1, mask, rate))
-    return ups
+    return (ups, lows) if return_lowres else ups
 
 
 def _cbr3d(sd: SD, p: str, x: torch.Tensor, stride: int = 1, upsample: bool = False) -> torch.Tensor:

@@ -30,13 +30,14 @@ def _u(tag, *shape, lo=-1.0, hi=1.0):
 @pytest.mark.parametrize("B", [1, 2])
 def test_igev_config3_136x240_vs_oracle(R, B):
     """configs[2] per-sample shape: fmaps (B,128,136,240), guides at 1/8, 1/16, 1/32 -> group-wise volume -> HIP Conv3d
-    regulariser -> pyramids -> fused squeezer + soft-argmin -> 2 iterations of the IGEV loop (hidden 64, 576 correlation
-    channels, rate 4), every stage against the oracle (nndepth/models/igev_stereo/model.py:121-160, cost_volume.py:32-98)."""
+    regulariser -> pyramids -> fused squeezer + soft-argmin -> 8 iterations of the IGEV loop (hidden 64, 576 correlation
+    channels, rate 4), every stage against the oracle (nndepth/models/igev_stereo/model.py:121-160, cost_volume.py:32-98).
+    The loop is conditioned (below) so that the coordinates stay on the 240-wide map and the 1e-4 bar is an absolute one."""
     from nndepth_amd import ops, weightgen
     from nndepth_amd.blocks import BasicUpdateBlock
     from nndepth_amd.cost_volume import GeometryAwareCostVolume
     from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
-    C, G, H, W, iters = 128, 8, 136, 240, 2
+    C, G, H, W, iters = 128, 8, 136, 240, 8
     # right map = left map shifted by a few pixels + noise, so the volume has a ridge and the soft-argmin a real peak
     f1 = _u(f"c3f1_{B}", B, C, H, W)
     f2 = torch.roll(f1, -7, dims=-1) + 0.1 * _u(f"c3f2_{B}", B, C, H, W)
@@ -44,6 +45,13 @@ def test_igev_config3_136x240_vs_oracle(R, B):
     net, inp = torch.tanh(_u(f"c3n_{B}", B, 64, H, W, lo=-2, hi=2)), torch.relu(_u(f"c3i_{B}", B, 64, H, W))
     reg_sd = weightgen.fill_state_dict(R.cost_volume_filter_spec("igev.cv_regularizer"))
     ub_sd = weightgen.fill_state_dict(R.update_block_spec("update_block", 64, 576, 64, 1, 4))
+    # IGEV feeds the ABSOLUTE coordinate (0..239) through the motion encoder's 7x7 conv and adds the flow head's output to it
+    # every iteration (reference quirk Q5): with fan-in-scaled random weights that loop gain is far above one (round 2 saw
+    # |coords| = 638 after 2 iterations: every lookup tap clamped, nothing left to test).  Scale the two ends of that loop so
+    # that the recurrence moves the coordinates by O(0.1) px per iteration and they stay on the map.
+    ub_sd["update_block.encoder.convf1.weight"] = ub_sd["update_block.encoder.convf1.weight"] / 64.0
+    ub_sd["update_block.flow_head.conv2.weight"] = ub_sd["update_block.flow_head.conv2.weight"] * 0.02
+    ub_sd["update_block.flow_head.conv2.bias"] = ub_sd["update_block.flow_head.conv2.bias"] * 0.02
     # random regulariser weights damp the volume to |geo| ~ 0.1: scale the squeezer so that the softmax has real peaks
     sq_w = weightgen.make_tensor("igev.cv_squeezer.weight", (1, G, 3, 3, 3)) * 500.0
     sq_b = weightgen.make_tensor("igev.cv_squeezer.bias", (1,))
@@ -52,7 +60,11 @@ def test_igev_config3_136x240_vs_oracle(R, B):
         gvol = R.cost_volume_filter(reg_sd, "igev.cv_regularizer", fvol.permute(0, 1, 4, 2, 3), guides)
         fp, gp = R.igev_pyramids(fvol, gvol, 4)
         init = R.igev_init_disparity(torch.nn.functional.conv3d(gvol, sq_w, sq_b, padding=1).squeeze(1))
-        exp = R.igev_refine(ub_sd, "update_block", fp, gp, net, inp, init, iters)
+        exp, exp_low = R.igev_refine(ub_sd, "update_block", fp, gp, net, inp, init, iters, return_lowres=True)
+    lo_c, hi_c = min(c.min().item() for c in exp_low), max(c.max().item() for c in exp_low)
+    inside = float(np.mean([((c >= 0) & (c <= W - 1)).float().mean().item() for c in exp_low]))
+    print(f"\n[config3 B={B}] coordinates over {iters} iterations: {lo_c:.1f} .. {hi_c:.1f} on a {W}-wide map, {100 * inside:.1f} % inside [0, W-1]")
+    assert inside >= 0.95 and lo_c > -16 and hi_c < W + 16
     del fvol, gvol
 
     reg = CostVolumeFilterNetwork(G, [40, 80, 160]).eval()
@@ -88,8 +100,12 @@ def test_igev_config3_136x240_vs_oracle(R, B):
                              coords.to(DEV), G, 4, 4).cpu()
     assert torch.equal(got_lk, R.igev_lookup(fp, gp, coords, G, 4, 4))
     del got_lk
-    # loop: 2 iterations from the oracle's initial disparity (isolates the loop from the init error above)
-    # (both arithmetics: 32 640 pixels = 510 workgroup columns, the split kernel's large-map workgroup shapes)
+    # loop: 8 iterations from the oracle's initial disparity (isolates the loop from the init error above)
+    # (all arithmetics: 32 640 pixels = 510 workgroup columns, the split kernel's large-map workgroup shapes).
+    # Bar: the 1/4-resolution coordinates (the loop's state; |c| < 256: one ulp = 1.5e-5) <= 1e-4 ABSOLUTE after every iteration
+    # count checked; the full-resolution output is 4 x the coordinate (up to ~960: one ulp = 6.1e-5) and a 9-term convex
+    # combination of it, so it is held to 4 ulp of its largest value (2.4e-4) — the reference's own 1-thread vs 8-thread
+    # outputs differ by 1.8e-4 at that magnitude (tests/golden/REPORT_realdata.txt).
     for ar in ("fp32", "bf16x3", "fp16x2"):
         ub = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4, arithmetic=ar)
         ub.load_state_dict({k[len("update_block."):]: v for k, v in ub_sd.items()})
@@ -98,11 +114,81 @@ def test_igev_config3_136x240_vs_oracle(R, B):
         up, low, _ = eng.refine_igev(*args, disp_init=init.to(DEV))
         up_il, low_il, _ = eng.refine_igev(*args, disp_init=init.to(DEV), interleaved=cv.interleaved())
         errs = [(up[i].cpu() - exp[i]).abs().max().item() for i in range(iters)]
-        scale = max(1.0, exp[-1].abs().max().item() / 40)
-        print(f"[config3 B={B} {ar}] loop max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs),
-              f"(|coords| max {exp[-1].abs().max().item():.0f})")
-        assert max(errs) <= 2e-4 * scale
+        e_low = {iters: (low.cpu() - exp_low[-1]).abs().max().item()}
+        for k in (1, 4):
+            _, low_k, _ = eng.refine_igev(*args[:-1], k, disp_init=init.to(DEV), keep_all=False)
+            e_low[k] = (low_k.cpu() - exp_low[k - 1]).abs().max().item()
+        ulp_up = float(np.spacing(np.float32(exp[-1].abs().max().item())))
+        print(f"[config3 B={B} {ar}] 1/4-res coordinates max-abs after 1 / 4 / {iters} iterations: {e_low[1]:.2e} {e_low[4]:.2e} {e_low[iters]:.2e};",
+              "up_disp per iteration:", " ".join(f"{e:.2e}" for e in errs), f"(|up| max {exp[-1].abs().max().item():.0f}, ulp {ulp_up:.1e})")
+        assert max(e_low.values()) <= 1e-4
+        assert max(errs) <= 4 * ulp_up
         assert torch.equal(up_il, up) and torch.equal(low_il, low)  # interleaved gather == reference-layout gather, bit for bit
+
+
+def test_igev_config3_batch8_full_size_properties(R):
+    """configs[2] at its stated batch: 8 samples of 136x240 x 128 channels through the whole HIP path — group-wise volume,
+    Conv3d regulariser, both pyramids (2 x 3.9 GB), the group-interleaved copy (1.94 G floats: the index range of the gather
+    kernels), fused squeezer + soft-argmin, 8 iterations of the loop — in one call.  No CPU oracle finishes this in test
+    time, so the size-independent properties carry it: (i) every sample of the batch equals the same sample run alone
+    (k = 0, 5, 7; the batch index enters addresses only), (ii) pooled levels == avg_pool1d of the level below, bit-exact,
+    (iii) the loop over the interleaved copy == the loop over the reference-layout pyramids, bit for bit.  The single-sample
+    path itself is pinned to the oracle by test_igev_config3_136x240_vs_oracle."""
+    from nndepth_amd import ops, weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.cost_volume import GeometryAwareCostVolume
+    from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
+    B, C, G, H, W, iters = 8, 128, 8, 136, 240, 8
+    f1 = _u("c3b8f1", B, C, H, W)
+    f2 = torch.roll(f1, -7, dims=-1) + 0.1 * _u("c3b8f2", B, C, H, W)
+    guides = [_u(f"c3b8g{j}", B, c, H >> (j + 1), W >> (j + 1), lo=0.0, hi=1.0) for j, c in enumerate((40, 80, 160))]
+    net, inp = torch.tanh(_u("c3b8n", B, 64, H, W, lo=-2, hi=2)), torch.relu(_u("c3b8i", B, 64, H, W))
+    reg_sd = weightgen.fill_state_dict(R.cost_volume_filter_spec("igev.cv_regularizer"))
+    ub_sd = weightgen.fill_state_dict(R.update_block_spec("update_block", 64, 576, 64, 1, 4))
+    ub_sd["update_block.encoder.convf1.weight"] = ub_sd["update_block.encoder.convf1.weight"] / 64.0  # conditioning: see the test above
+    ub_sd["update_block.flow_head.conv2.weight"] = ub_sd["update_block.flow_head.conv2.weight"] * 0.02
+    ub_sd["update_block.flow_head.conv2.bias"] = ub_sd["update_block.flow_head.conv2.bias"] * 0.02
+    sq_w = weightgen.make_tensor("igev.cv_squeezer.weight", (1, G, 3, 3, 3)) * 500.0
+    sq_b = weightgen.make_tensor("igev.cv_squeezer.bias", (1,))
+    reg = CostVolumeFilterNetwork(G, [40, 80, 160]).eval()
+    reg.load_state_dict({k[len("igev.cv_regularizer."):]: v for k, v in reg_sd.items()}, strict=True)
+    reg = reg.to(DEV)
+    d = [x.to(DEV) for x in (f1, f2, net, inp)] + [[g.to(DEV) for g in guides]]
+    cv8 = GeometryAwareCostVolume(d[0], d[1], d[4], reg, 4, 4, G)
+    for views in (cv8.feat_corr_cv, cv8.geo_aware_cv):  # (ii)
+        for lvl in range(1, 5):
+            assert torch.equal(views[lvl], torch.nn.functional.avg_pool1d(views[lvl - 1], 2, stride=2)), lvl
+    init8 = ops.igev_init_disparity(cv8.geo_aware_cv[0], sq_w, sq_b, B, G, H, W, W)
+    il8 = cv8.interleaved()
+    assert il8.numel() > 1.9e9  # 1.94 G floats: 32-bit element indices would wrap at 2.15 G
+    n1 = G * H * W  # pyramid rows of one sample
+    for ar in ("fp32", "fp16x2"):
+        ub = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4, arithmetic=ar)
+        ub.load_state_dict({k[len("update_block."):]: v for k, v in ub_sd.items()})
+        eng = ub.to(DEV).sync_engine(DEV)
+        up8, low8, net8 = eng.refine_igev(cv8._feat, cv8._geo, G, 4, 4, d[2], d[3], 4, iters, disp_init=init8, interleaved=il8)
+        up8r, low8r, _ = eng.refine_igev(cv8._feat, cv8._geo, G, 4, 4, d[2], d[3], 4, iters, disp_init=init8)
+        assert torch.equal(up8, up8r) and torch.equal(low8, low8r)  # (iii)
+        del up8r, low8r
+        inside = ((low8 >= 0) & (low8 <= W - 1)).float().mean().item()
+        print(f"\n[config3 batch 8 {ar}] coordinates after {iters} iterations {low8.min().item():.1f} .. {low8.max().item():.1f}, {100 * inside:.1f} % on the map")
+        assert torch.isfinite(up8).all() and inside >= 0.95
+        for k in (0, 5, 7):  # (i)
+            cv1 = GeometryAwareCostVolume(d[0][k:k + 1].contiguous(), d[1][k:k + 1].contiguous(), [g[k:k + 1].contiguous() for g in d[4]], reg, 4, 4, G)
+            for lvl in range(4):
+                for v8, v1 in ((cv8.feat_corr_cv, cv1.feat_corr_cv), (cv8.geo_aware_cv, cv1.geo_aware_cv)):
+                    e = (v8[lvl][k * n1:(k + 1) * n1] - v1[lvl]).abs().max().item()
+                    assert e <= 1e-6 * max(1.0, v1[lvl].abs().max().item()), (k, lvl, e)
+            init1 = ops.igev_init_disparity(cv1.geo_aware_cv[0], sq_w, sq_b, 1, G, H, W, W)
+            e_init = (init1 - init8[k:k + 1]).abs().max().item()
+            up1, low1, net1 = eng.refine_igev(cv1._feat, cv1._geo, G, 4, 4, d[2][k:k + 1].contiguous(), d[3][k:k + 1].contiguous(), 4, iters,
+                                              disp_init=init8[k:k + 1].contiguous(), interleaved=cv1.interleaved())
+            e_low = (low1 - low8[k:k + 1]).abs().max().item()
+            e_up = (up1[:, 0] - up8[:, k]).abs().max().item()
+            print(f"[config3 batch 8 {ar}] sample {k} alone vs in the batch: init {e_init:.1e}, coordinates {e_low:.1e}, up_disp {e_up:.1e}")
+            assert e_init <= 1e-3 and e_low <= 2e-5 and e_up <= 2.5e-4
+            del cv1
+    del cv8, il8
 
 
 # ------------------------------------------------------------------------------------------ config 4: KITTI batch 8
