@@ -43,7 +43,8 @@ struct Switches {
     bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, no_conv1x1_stream,
         conv_verbose, debug_sync;
     unsigned split_mask;              // NND_SPLIT_MASK: bit = ConvId of the update-block convs that may take the split kernel
-    int split_ny, split_ks;           // NND_SPLIT_CFG=ny,ks (<= 0: the picker decides)
+    int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
+    bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
     int conv_p, conv_ks, conv_wco;    // NND_CONV_CFG=p,ks,wco / NND_CONV_P
     int agcl_pb;                      // NND_AGCL_PB
 };

@@ -26,10 +26,7 @@
 //
 // Replaces (when selected) the same nn.Conv2d calls as conv_mfma.hip: nndepth/blocks/update_block.py:57-65,26-36,97-112,
 // nndepth/blocks/gru.py:22-37,53-61.
-#include "common.h"
-#include "conv_epilogue.h"
-#include "layout.h"
-#include "split_arith.h"
+#include "conv_split_kernel.h"
 
 #include <atomic>
 #include <cmath>
@@ -38,379 +35,8 @@
 
 namespace nnd {
 
-#ifndef NND_SPLIT_AD
-#define NND_SPLIT_AD 1      // steps of lookahead of the weight-fragment stream
-#endif
-#ifndef NND_SPLIT_BSLOTS
-#define NND_SPLIT_BSLOTS 2  // register sets of the activation fragments (lookahead = sets - 1 units of 6 MFMAs); 3 measured equal, spills
-#endif
-
-#ifdef NND_DBG_STAMPS
-// debug build only: per-workgroup phase timestamps (s_memrealtime, 100 MHz) for scripts/stamps_split.py
-__device__ unsigned long long g_split_stamps[4096 * 8];
-#define NND_SSTAMP(i)                                                                                  \
-    do {                                                                                               \
-        if (threadIdx.x == 0) {                                                                        \
-            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
-            if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();        \
-        }                                                                                              \
-    } while (0)
-// shader-clock stamps (s_memtime) in slots 5 / 6 next to the real-time stamps 1 / 2: in-kernel clock of the K loop
-#define NND_SCLOCK(i)                                                                                  \
-    do {                                                                                               \
-        if (threadIdx.x == 0) {                                                                        \
-            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
-            if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memtime();            \
-        }                                                                                              \
-    } while (0)
-#else
-#define NND_SSTAMP(i)
-#define NND_SCLOCK(i)
-#endif
-
-__host__ __device__ constexpr int split_pos_bytes(int NS) { return NS * 32 + 16; }
-__host__ __device__ constexpr int split_row_bytes(int PC, int NS) {
-    int rb = (PC * split_pos_bytes(NS) + 15) / 16;
-    while (rb % 16 != 8) ++rb;
-    return rb * 16;
-}
-
-// lane (0..31 of a half-wave) -> pixel index r*8 + c of the 4x8 sub-tile: the two lane groups that ds_read_b128 serves in
-// separate cycles get rows {0,1} and rows {2,3}
-__device__ __forceinline__ int lane_pixel(int l31) {
-    const bool g0 = (l31 < 4) || (l31 >= 12 && l31 < 16) || (l31 >= 20 && l31 < 28);
-    const int idx = g0 ? (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12)) : (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16));
-    return (g0 ? 0 : 16) + idx;
-}
-
-// split_pieces<NS> / split_mfma_step<NS>: split_arith.h (NS = 3: bf16 pieces, NS = 2: range-scaled fp16 pieces)
-
-template <int KH, int KW, int NS, int P, int NU>
-__global__ void __launch_bounds__(768) conv_split_kernel(ConvArgs a) {
-    constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
-    constexpr int PR = 4 + KH - 1, PC = 8 + KW - 1, NPOS = PR * PC;
-    constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PC, NS), SUBB = PR * ROWB;
-    constexpr int NPROD = NS * (NS + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    NND_SSTAMP(0);
-
-    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = a.wco, ks = a.ks;
-    const int cbi = wave % wco, kj = wave / wco;
-    const int h2 = lane >> 5, l31 = lane & 31;
-    const int pxl = lane_pixel(l31), r = pxl >> 3, c = pxl & 7;
-    const int cb = blockIdx.y * wco + cbi;
-    const bool active = cb * 32 < a.Cout;
-    const int b = blockIdx.z;
-    const int Hin = a.Hin, Win = a.Win;
-    const long SP = a.ls.plane;
-    const int SCH = ks * 16;  // channels per super-chunk
-    // fp16x2: the power-of-two scale that undoes the range scaling of both operands (packed behind the bias), requested now
-    float oscale = 1.f;
-    if constexpr (NS == 2) oscale = a.bias[((a.Cout + 31) >> 5) << 5];
-
-    int ty0[P], tx0[P];
-#pragma unroll
-    for (int pp = 0; pp < P; ++pp) {
-        const int t = blockIdx.x * P + pp;
-        const bool valid = t < a.npos;  // npos = number of sub-tiles of one image
-        ty0[pp] = valid ? (t / a.tiles_x) * 4 : (1 << 20);  // an absent sub-tile lies outside the image: staged as zeros, never stored
-        tx0[pp] = valid ? (t % a.tiles_x) * 8 : 0;
-    }
-
-    // ---- staging units of this thread: unit = (sub-tile, patch position, 8 consecutive channels of the super-chunk)
-    const int nunits = P * NPOS * 2 * ks;
-    int goff[NU], loff[NU], cho[NU];
-    bool inimg[NU], own[NU];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        const int u = tid + i * nthreads;
-        own[i] = u < nunits;
-        const int pos = u % NPOS, rest = u / NPOS;
-        const int pp = rest % P, oct = rest / P;
-        const int pr = pos / PC, pc = pos - pr * PC;
-        int gy = 0, gx = 0;
-#pragma unroll
-        for (int q = 0; q < P; ++q)
-            if (q == pp) {
-                gy = ty0[q] + pr - PH;
-                gx = tx0[q] + pc - PW;
-            }
-        inimg[i] = own[i] && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
-        goff[i] = inimg[i] ? (int)pix_off(a.ls, gy, gx) : 0;
-        loff[i] = (oct >> 1) * (P * SUBB) + pp * SUBB + pr * ROWB + pc * PS + (oct & 1) * 16;
-        cho[i] = oct * 8;
-    }
-
-    f32x16 acc[P];
-#pragma unroll
-    for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[pp][i] = 0.f;
-
-    const int nchunks = a.nchunks;  // 16-channel chunks
-    const int nsuper = (nchunks + ks - 1) / ks;
-    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(active ? cb : 0) * nchunks * (NT * NS * 64) + lane;
-    float stage[NU][8];
-
-    auto chunk_src = [&](int K, const float*& src, int& climit) {
-        const int cbase = K * SCH;
-        if (cbase < a.c0) {
-            src = a.src0 + b * a.bs0 + (long)cbase * SP;
-            climit = a.c0 - cbase;
-        } else {
-            const int cc = cbase - a.c0;
-            src = a.src1 + b * a.bs1 + (long)cc * SP;
-            climit = a.c1 - cc;
-        }
-    };
-    // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_unit.
-    const bool c4s = a.ls.ci == 4;  // 4-channel-interleaved source: a unit's 8 channels are two 16-B loads
-    auto load_unit = [&](int K, int i) {
-        const float* src;
-        int climit;
-        chunk_src(K, src, climit);
-        if (c4s) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int ci = cho[i] + 4 * g;  // multiple of 4: channel group ci/4 starts at ci*SP, like a planar channel
-                const float4 t = *reinterpret_cast<const float4*>(src + ((inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u));
-                stage[i][4 * g] = t.x; stage[i][4 * g + 1] = t.y; stage[i][4 * g + 2] = t.z; stage[i][4 * g + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ci = cho[i] + j;
-                stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
-            }
-        }
-    };
-    auto store_unit = [&](int K, int i) {
-        const float* src;
-        int climit;
-        chunk_src(K, src, climit);
-        unsigned char* buf = lds_raw + (K & 1) * (ks * P * SUBB);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (inimg[i] && cho[i] + j < climit) ? stage[i][j] : 0.f;
-        uint4 pieces[NS];
-        split_pieces<NS>(v, pieces);
-        if (own[i]) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(buf + loff[i] + s * 32) = pieces[s];
-        }
-    };
-    auto load_x = [&](int K) {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) load_unit(K, i);
-    };
-    auto store_x = [&](int K) {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) store_unit(K, i);
-    };
-    auto a_ptr = [&](int K) {
-        int ch = K * ks + kj;
-        ch = ch < nchunks ? ch : 0;  // waves past the last chunk re-read chunk 0: harmless, their MFMAs are skipped
-        return wbase + (size_t)ch * (NT * NS * 64);
-    };
-    auto load_a = [&](uint4 (&dst)[NS], const uint4* wc, int t) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) dst[s] = wc[(t * NS + s) * 64];
-    };
-
-    const int lane_base = kj * (P * SUBB) + r * ROWB + c * PS + h2 * 16;
-
-    // A fragments: a ring of AD + 1 register sets indexed by the global step g = K*NT + t; set g % NA holds step g, the
-    // loads of step g + AD are issued when step g starts (AD steps of MFMAs cover the L2 latency of the weight stream)
-    constexpr int AD = (NND_SPLIT_AD < NT ? NND_SPLIT_AD : NT), NA = AD + 1;
-    uint4 abuf[NA][NS];
-#pragma unroll
-    for (int g = 0; g < AD; ++g) load_a(abuf[g], a_ptr(0), g);
-    load_x(0);
-    store_x(0);
-    __syncthreads();
-    NND_SSTAMP(1);
-    NND_SCLOCK(5);
-
-    auto chunk = [&](int K, auto par_c) {
-        constexpr int par = decltype(par_c)::value;
-        const bool more = (K + 1 < nsuper);
-#ifndef NND_SPLIT_NO_STAGE
-        if (more) load_x(K + 1);
-#endif
-        const uint4* wc = a_ptr(K);
-        const uint4* wn = a_ptr(more ? K + 1 : K);  // past the end: re-reads the last chunk, never used
-        const bool mine = K * ks + kj < nchunks;
-        const unsigned char* xb = lds_raw + (K & 1) * (ks * P * SUBB) + lane_base;
-        // B fragments rotate through 3 slots at (tap, sub-tile) granularity: unit u = t*P + pp lives in slot u % 3 and the
-        // reads of unit u + 2 are issued when unit u starts (its slot was freed by unit u - 1)
-        constexpr int NUNIT = NT * P, NSLOT = NND_SPLIT_BSLOTS;
-        uint4 bq[NSLOT][NS];
-        auto read_b = [&](int u, uint4 (&dst)[NS]) {
-            const int t = u / P, pp = u % P;
-            const int dy = t / KW, dx = t % KW;
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + dy * ROWB + dx * PS + s * 32);
-        };
-#pragma unroll
-        for (int u = 0; u < NSLOT - 1 && u < NUNIT; ++u) read_b(u, bq[u]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            uint4(&ac)[NS] = abuf[(par + t) % NA];
-            uint4(&an)[NS] = abuf[(par + t + AD) % NA];
-#ifndef NND_SPLIT_NO_ALOAD
-            if (t + AD < NT) load_a(an, wc, t + AD);
-            else load_a(an, wn, t + AD - NT);
-#else
-            for (int s = 0; s < NS; ++s) an[s] = ac[s];
-#endif
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) {
-                const int u = t * P + pp;
-                if (u + NSLOT - 1 < NUNIT) read_b(u + NSLOT - 1, bq[(u + NSLOT - 1) % NSLOT]);
-#ifndef NND_SPLIT_NO_MFMA
-                if (mine)
-#else
-                if (mine && acc[0][0] == 123.f)
-#endif
-                    split_mfma_step<NS>(ac, bq[u % NSLOT], acc[pp]);  // small products first (split_arith.h)
-            }
-        }
-#ifndef NND_SPLIT_NO_STAGE
-        if (more) store_x(K + 1);
-#endif
-        __syncthreads();
-    };
-    static_assert(NPROD == NS * (NS + 1) / 2, "product list");
-    // the ring phase of a chunk's first step, (K*NT) % NA, must be a compile-time constant: walk the chunks in periods
-    constexpr int STEP = NT % NA;
-    if constexpr (STEP == 0) {
-        for (int K = 0; K < nsuper; ++K) chunk(K, std::integral_constant<int, 0>{});
-    } else if constexpr (NA == 2) {
-        for (int K = 0; K < nsuper; K += 2) {
-            chunk(K, std::integral_constant<int, 0>{});
-            if (K + 1 < nsuper) chunk(K + 1, std::integral_constant<int, 1>{});
-        }
-    } else {
-        static_assert(NA == 3, "A-fragment ring of 2 or 3 register sets");
-        for (int K = 0; K < nsuper; K += 3) {
-            chunk(K, std::integral_constant<int, 0>{});
-            if (K + 1 < nsuper) chunk(K + 1, std::integral_constant<int, STEP>{});
-            if (K + 2 < nsuper) chunk(K + 2, std::integral_constant<int, (2 * STEP) % 3>{});
-        }
-    }
-
-    NND_SSTAMP(2);
-    NND_SCLOCK(6);
-    if constexpr (NS == 2) {  // exact: a power of two
-#pragma unroll
-        for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[pp][i] *= oscale;
-    }
-    int ys[P], xs[P];
-#pragma unroll
-    for (int pp = 0; pp < P; ++pp) {
-        ys[pp] = ty0[pp] + r;
-        xs[pp] = tx0[pp] + c;
-    }
-    float* red_all = reinterpret_cast<float*>(lds_raw);
-    constexpr int TS = P * 1024;
-    // intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier): every wave leaves
-    // its partial tile, slice kj then owns registers [kj*16/ks, (kj+1)*16/ks) of the summed tile for the epilogue
-    auto exchange = [&]() {
-        if (active) {
-            float* red = red_all + (size_t)(cbi * ks + kj) * TS + lane;
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) red[pp * 1024 + reg * 64] = acc[pp][reg];
-        }
-        __syncthreads();
-    };
-    // c4 destination: NG = 4/ks register groups per sub-tile.  What the epilogue reads (per-pixel bias map, h, z) is requested
-    // BEFORE the exchange — the fragment registers are dead — and arrives while the partial sums cross LDS.
-    auto finish_c4 = [&](auto ng_c) {
-        constexpr int NG = decltype(ng_c)::value;  // == 4 / ks, ks = 2 or 4
-        const int q0 = kj * NG;
-        EpiOpsC4<P, NG> eo;
-#ifndef NND_SPLIT_NO_EPI
-        if (active) epi_c4_load<P, NG>(a, cb, b, h2, q0, ys, xs, eo);
-#endif
-        exchange();
-        if (!active) return;
-        float4 cacc[P][NG];
-#pragma unroll
-        for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* red = red_all + (size_t)(cbi * ks) * TS + pp * 1024 + (4 * (q0 + j) + i) * 64 + lane;
-                    float sum = red[0];
-#pragma unroll
-                    for (int sl = 1; sl < 4 / NG; ++sl) sum += red[(size_t)sl * TS];
-                    v[i] = sum;
-                }
-                cacc[pp][j] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        NND_SSTAMP(3);
-#ifdef NND_SPLIT_NO_EPI
-        if (cacc[0][0].x != 123.456f) return;
-#endif
-        epi_c4_store<P, NG>(a, cacc, cb, b, h2, q0, eo);
-    };
-    if (a.ld.ci == 4) {
-        if (ks == 4) finish_c4(std::integral_constant<int, 1>{});
-        else if (ks == 2) finish_c4(std::integral_constant<int, 2>{});
-        else {  // no exchange to hide the loads behind
-            if (!active) return;
-            NND_SSTAMP(3);
-#ifdef NND_SPLIT_NO_EPI
-            if (acc[0][0] != 123.456f) return;
-#endif
-            conv_epilogue_c4<P>(a, acc, cb, b, h2, 0, 16, ys, xs);
-        }
-    } else {
-        if (ks > 1) exchange();
-        if (!active) return;
-        const int nreg = 16 / ks, reg0 = kj * nreg;
-        if (ks > 1) {
-            const float* red = red_all + (size_t)(cbi * ks) * TS + lane;
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (reg < reg0 || reg >= reg0 + nreg) continue;
-                    float sum = red[pp * 1024 + reg * 64];
-                    for (int j = 1; j < ks; ++j) sum += red[(size_t)j * TS + pp * 1024 + reg * 64];
-                    acc[pp][reg] = sum;
-                }
-        }
-        NND_SSTAMP(3);
-#ifdef NND_SPLIT_NO_EPI
-        if (acc[0][0] != 123.456f) return;
-#endif
-        conv_epilogue_planar<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
-    }
-#ifdef NND_DBG_STAMPS
-    __builtin_amdgcn_s_waitcnt(0);
-#endif
-    NND_SSTAMP(4);
-}
-
 // --------------------------------------------------------------------------- host side
 namespace {
-struct SplitCfg {
-    int ny, wco, ks, ntiles, tiles_x, nu;
-    size_t lds;
-};
-
-constexpr int SPLIT_P = 2, SPLIT_MAX_WAVES = 12;
-
 // fp16x2 pieces on the host: clang's _Float16 conversion is IEEE round-to-nearest-even including subnormal results
 uint16_t f16_rn(float x) {
     const _Float16 h = (_Float16)x;
@@ -437,21 +63,27 @@ float bf16_to_f(uint16_t h) {
     return f;
 }
 
-bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCfg* out) {
+// fast = the kernel's FAST regime is possible for this launch (c4 sources; checked per candidate: full super-chunks inside one
+// source).  P (sub-tiles per wave) is a search dimension there: each weight fragment feeds P MFMA groups, so a workgroup of
+// a output-channel blocks x P sub-tiles moves a x (weights of a block) + P x (patch of a sub-tile) through its CU's L2 path —
+// at 68x120 the 12-wave shapes of round 2 (3 x 2, 4 x 2, 6 x 2 blocks x sub-tiles) become 2 x 3, 2 x 4, 4 x 3.
+bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fast_ok, SplitCfg* out) {
     const int NS = L.arith;
     const int PR = 4 + L.KH - 1, PC = 8 + L.KW - 1;
     const size_t subb = (size_t)PR * split_row_bytes(PC, NS);
     const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
-    const long px_wgs = (long)cdiv(ntiles, SPLIT_P) * B;
-    int force_ny = switches().split_ny, force_ks = switches().split_ks;
+    int force_ny = switches().split_ny, force_ks = switches().split_ks, force_p = switches().split_p;
+    const bool forced = force_ny > 0 || force_ks > 0 || force_p > 0;
+    const long px_wgs2 = (long)cdiv(ntiles, 2) * B;
     // Short K (Cin <= 64: at most 4 chunks, the encoder's first residual stage): a workgroup is mostly prologue, exchange and
     // epilogue, so the best shape is the smallest one — no split K, all output-channel blocks in one workgroup (the patch is
     // staged once), 6 two-wave workgroups per CU covering each other's fixed phases.  Measured, 64 -> 64 3x3 at 272x480x2
     // (scripts/sweep_split_encoder.py): (ny,ks) = (1,1) 158 us | (1,2) 226 | (1,4) 326 | (2,1) 333; exact fp32 kernel 254.
     bool rule = false;
-    if (L.nchunks <= 4 && force_ny <= 0 && force_ks <= 0 && L.ncb <= SPLIT_MAX_WAVES) {
+    if (L.nchunks <= 4 && !forced && L.ncb <= SPLIT_MAX_WAVES) {
         force_ny = 1;
         force_ks = 1;
+        force_p = 2;
         rule = true;
     }
     // Many workgroup columns (>= 448: 136x240 maps, batch 8 at KITTI size, the encoder's first stages): the chip is filled
@@ -459,68 +91,70 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, SplitCf
     // epilogue); with a long K (>= 16 chunks) at most 4 output-channel blocks per workgroup, with a short K all of them (the
     // patch staging then dominates and is done once).  Measured with scripts/sweep_split.py at 48x156 batch 8 against the
     // cost model below: zr 312 -> 280 us, q 202 -> 165, convc2 412 -> 379, conv 246 -> 228 (profiles/r02_split_wg_shape_sweep.txt).
-    if (!rule && px_wgs >= 448 && force_ny <= 0 && force_ks <= 0 && L.ncb <= SPLIT_MAX_WAVES) {
+    if (!rule && px_wgs2 >= 448 && !forced && L.ncb <= SPLIT_MAX_WAVES) {
         rule = true;
         force_ks = 1;
         force_ny = 1;
+        force_p = 2;
         if (L.nchunks >= 16)
             while (force_ny < L.ncb && (L.ncb % force_ny != 0 || L.ncb / force_ny > 4)) ++force_ny;
     }
-    auto search = [&](int f_ny, int f_ks) {
+    auto search = [&](int f_ny, int f_ks, int f_p) {
         double best = 1e30;
         bool found = false;
-        for (int ny = 1; ny <= L.ncb; ++ny) {
-            if (L.ncb % ny != 0 || (f_ny > 0 && ny != f_ny)) continue;
-            const int wco = L.ncb / ny;
-            for (int ks : {1, 2, 4}) {
-                if (f_ks > 0 && ks != f_ks) continue;
-                const int waves = wco * ks;
-                if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
-                if (c1 > 0 && c0 % (ks * 16) != 0) continue;
-                const int nu = cdiv(SPLIT_P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread (2 built, 4 for 1-2 waves)
-                if (nu > 4) continue;
-                size_t lds = (size_t)2 * ks * SPLIT_P * subb;
-                const size_t red = ks > 1 ? (size_t)waves * SPLIT_P * 4096 : 0;
-                if (red > lds) lds = red;
-                if (lds > 160 * 1024) continue;
-                int wg_per_cu = (int)((160 * 1024) / lds);
-                if (wg_per_cu > SPLIT_MAX_WAVES / waves) wg_per_cu = SPLIT_MAX_WAVES / waves;
-                if (wg_per_cu < 1) wg_per_cu = 1;
-                const double rounds = std::ceil((double)px_wgs * ny / (256.0 * wg_per_cu));
-                const double simd_waves = std::ceil(waves * wg_per_cu / 4.0);
-                double t = rounds * simd_waves * cdiv(L.nchunks, ks);
-                t *= 1.0 + 0.03 * (ks - 1);       // split-K exchange
-                t *= 1.0 + 0.02 * (4 - (wco < 4 ? wco : 4));  // fewer waves share one staged patch
-                if (nu > 2) t *= 1.2;                          // register-heavy staging variant
-                if (t < best) {
-                    best = t;
-                    *out = {ny, wco, ks, ntiles, tiles_x, nu <= 2 ? 2 : 4, lds};
-                    found = true;
+        for (int P : {2, 3, 4}) {
+            // P = 3 / 4 only when forced (NND_SPLIT_CFG): measured at 68x120 with fp16x2 (profiles/r03_split_shape_sweep_68x120.txt)
+            // the 8-wave P = 3 / 4 shapes lose to the 12-wave P = 2 ones on every layer (convc2 29.4 vs 26.2 us, zr 26.3 vs 26.1,
+            // fhm 29.4 vs 27.0): with the weight ring pinned, the L2 path is no longer what the K loop waits for
+            if ((f_p > 0 && P != f_p) || (f_p <= 0 && P != 2)) continue;
+            const long px_wgs = (long)cdiv(ntiles, P) * B;
+            for (int ny = 1; ny <= L.ncb; ++ny) {
+                if (L.ncb % ny != 0 || (f_ny > 0 && ny != f_ny)) continue;
+                const int wco = L.ncb / ny;
+                for (int ks : {1, 2, 4}) {
+                    if (f_ks > 0 && ks != f_ks) continue;
+                    const int waves = wco * ks;
+                    if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
+                    if (c1 > 0 && c0 % (ks * 16) != 0) continue;
+                    const bool fast = fast_ok && L.nchunks % ks == 0;
+                    if (P > 2 && (!fast || waves > 8 || L.KH * L.KW == 1)) continue;  // P = 3 / 4: FAST kernels with <= 512 threads
+                    const int nu = cdiv(P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread
+                    if (nu > 4 || (P == 3 && nu > 3)) continue;
+                    size_t lds = (size_t)2 * ks * P * subb;
+                    const size_t red = ks > 1 ? (size_t)waves * P * 4096 : 0;
+                    if (red > lds) lds = red;
+                    if (lds > 160 * 1024) continue;
+                    const int max_waves = P > 2 ? 8 : SPLIT_MAX_WAVES;
+                    int wg_per_cu = (int)((160 * 1024) / lds);
+                    if (wg_per_cu > max_waves / waves) wg_per_cu = max_waves / waves;
+                    if (wg_per_cu < 1) wg_per_cu = 1;
+                    const double rounds = std::ceil((double)px_wgs * ny / (256.0 * wg_per_cu));
+                    const double simd_waves = std::ceil(waves * wg_per_cu / 4.0);
+                    // matrix time of the busiest SIMD, in units of one sub-tile x one 16-channel chunk
+                    double t = rounds * simd_waves * cdiv(L.nchunks, ks) * P / 2.0;
+                    t *= 1.0 + 0.03 * (ks - 1);       // split-K exchange
+                    t *= 1.0 + 0.02 * (4 - (wco < 4 ? wco : 4));  // fewer waves share one staged patch
+                    if (nu > 2 && P == 2) t *= 1.2;                // register-heavy staging variant
+                    if (t < best) {
+                        best = t;
+                        *out = {ny, wco, ks, P, ntiles, tiles_x, P == 2 ? (nu <= 2 ? 2 : 4) : (nu <= 3 ? 3 : 4), fast, lds};
+                        found = true;
+                    }
                 }
             }
         }
         return found;
     };
-    if (search(force_ny, force_ks)) return true;
-    return rule && search(-1, -1);  // the regime rule's shape does not exist for this layer: the cost model decides
-}
-
-template <int KH, int KW, int NS, int NU>
-int launch_split_nu(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    auto kern = conv_split_kernel<KH, KW, NS, SPLIT_P, NU>;
-    if (lds > 64 * 1024) {
-        static std::atomic<unsigned> raised{0};
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
-    }
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-    return NND_OK;
-}
-template <int KH, int KW, int NS>
-int launch_split_one(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
-    if (cfg.nu <= 2) return launch_split_nu<KH, KW, NS, 2>(a, grid, block, cfg.lds, stream);
-    return launch_split_nu<KH, KW, NS, 4>(a, grid, block, cfg.lds, stream);
+    if (search(force_ny, force_ks, force_p)) return true;
+    return rule && search(-1, -1, -1);  // the regime rule's shape does not exist for this layer: the cost model decides
 }
 }  // namespace
+
+// the kernel instantiations live in conv_split_ns2.hip / conv_split_ns3.hip
+template <>
+int launch_split_ns<2>(const ConvArgs& a, const SplitCfg& cfg, int KH, int KW, dim3 grid, dim3 block, hipStream_t stream);
+template <>
+int launch_split_ns<3>(const ConvArgs& a, const SplitCfg& cfg, int KH, int KW, dim3 grid, dim3 block, hipStream_t stream);
 
 bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith) {
     if ((arith != 3 && arith != 2) || stride != 1 || Cin % 16 != 0) return false;
@@ -534,7 +168,10 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     NND_REQUIRE(L.CI_T == 16 && L.nchunks * 16 == L.Cin, "conv_split: layer was not planned for 16-channel chunks");
     NND_REQUIRE((long)(L.Cin + 64) * tiled_plane(H, W) < (1L << 31), "conv_split: plane offsets exceed 32 bits");
     SplitCfg cfg;
-    NND_REQUIRE(pick_split(L, io.src0.C, io.src1.C, B, H, W, &cfg), "conv_split: no configuration for %dx%d Cin=%d (%d+%d)", L.KH,
+    // FAST regime: both sources c4 tile-major (the refinement loops' own tensors); per candidate shape the picker also requires
+    // full super-chunks that never straddle the two sources.  NND_SPLIT_NO_FAST (diagnostic) keeps the generic kernel.
+    const bool fast_ok = io.src_c4 && io.src_tiled && !switches().split_no_fast;
+    NND_REQUIRE(pick_split(L, io.src0.C, io.src1.C, B, H, W, fast_ok, &cfg), "conv_split: no configuration for %dx%d Cin=%d (%d+%d)", L.KH,
                 L.KW, L.Cin, io.src0.C, io.src1.C);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -558,23 +195,15 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     NND_REQUIRE(epi != EPI_AFFINE || a.cscale, "conv_split: EPI_AFFINE needs a packed scale vector");
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks; a.npos = cfg.ntiles;
     a.scale = io.scale;
-    dim3 grid(cdiv(cfg.ntiles, SPLIT_P), cfg.ny, B), block(64 * cfg.wco * cfg.ks);
+    dim3 grid(cdiv(cfg.ntiles, cfg.P), cfg.ny, B), block(64 * cfg.wco * cfg.ks);
     const bool verbose = switches().conv_verbose;
     if (verbose)
-        fprintf(stderr, "[nnd] conv_split %dx%d Cin=%d Cout=%d pieces=%d: ny=%d, wco=%d, ks=%d, grid %ux%ux%u, lds %zu B\n", L.KH, L.KW,
-                L.Cin, L.Cout, L.arith, cfg.ny, cfg.wco, cfg.ks, grid.x, grid.y, grid.z, cfg.lds);
-    int rc = NND_ERR_UNSUPPORTED;
-    if (L.arith == 3) {
-        if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 3>(a, cfg, grid, block, stream);
-        else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 3>(a, cfg, grid, block, stream);
-        else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 3>(a, cfg, grid, block, stream);
-        else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 3>(a, cfg, grid, block, stream);
-    } else {
-        if (L.KH == 3 && L.KW == 3) rc = launch_split_one<3, 3, 2>(a, cfg, grid, block, stream);
-        else if (L.KH == 1 && L.KW == 5) rc = launch_split_one<1, 5, 2>(a, cfg, grid, block, stream);
-        else if (L.KH == 5 && L.KW == 1) rc = launch_split_one<5, 1, 2>(a, cfg, grid, block, stream);
-        else if (L.KH == 1 && L.KW == 1) rc = launch_split_one<1, 1, 2>(a, cfg, grid, block, stream);
-    }
+        fprintf(stderr, "[nnd] conv_split %dx%d Cin=%d Cout=%d pieces=%d: ny=%d, wco=%d, ks=%d, P=%d, nu=%d%s, grid %ux%ux%u, lds %zu B\n", L.KH,
+                L.KW, L.Cin, L.Cout, L.arith, cfg.ny, cfg.wco, cfg.ks, cfg.P, cfg.nu, cfg.fast ? ", fast" : "", grid.x, grid.y, grid.z, cfg.lds);
+    int rc = L.arith == 3 ? launch_split_ns<3>(a, cfg, L.KH, L.KW, grid, block, stream)
+                          : launch_split_ns<2>(a, cfg, L.KH, L.KW, grid, block, stream);
+    NND_REQUIRE(rc != NND_ERR_UNSUPPORTED, "conv_split: shape %dx%d P=%d nu=%d %s is not instantiated", L.KH, L.KW, cfg.P, cfg.nu,
+                cfg.fast ? "fast" : "generic");
     if (rc != NND_OK) return rc;
     NND_LAUNCH_CHECK();
     return NND_OK;
@@ -889,9 +518,6 @@ int launch_flow_branch(const ConvLayer& f2, const float* blob, const float* w7t,
 #ifdef NND_DBG_STAMPS
 extern "C" int nnd_debug_read_fb_stamps(unsigned long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fb_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
-}
-extern "C" int nnd_debug_read_split_stamps(unsigned long long* host, int n) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
 #endif
 }  // namespace nnd

@@ -1,0 +1,495 @@
+// conv_split_kernel: implicit-GEMM 2-D convolution (stride 1, zero "same" padding) on the gfx950 16-bit MFMA with fp32
+// operands carried as split 16-bit pieces (split_arith.h).  Design notes: conv_split.hip (header comment), DESIGN.md §4.
+// This header holds the kernel template and its launcher; it is instantiated per arithmetic in conv_split_ns2.hip (fp16x2)
+// and conv_split_ns3.hip (bf16x3) so that the two sets compile in parallel.
+//
+// Template parameters
+//   KH, KW  kernel shape (3x3, 1x5, 5x1, 1x1)
+//   NS      pieces per fp32 operand (3: bf16, 2: range-scaled fp16)
+//   P       4x8-pixel sub-tiles per wave (each weight fragment feeds P MFMA groups): 2, 3 or 4
+//   NU      staging units per thread (unit = patch position x 8 channels)
+//   FAST    the regime of the refinement loops' own tensors, decided by the host: both sources in the 4-channel-interleaved
+//           tile-major layout, every super-chunk of ks*16 channels full and inside one source.  Then nothing in the K loop is
+//           a run-time branch — the walk over (tap, sub-tile) is straight-line code whose waits the compiler can count exactly
+//           (round 2's kernel guarded every MFMA group with a wave-uniform `mine` test and chose the load form per unit at run
+//           time: the walk was cut into ~20 basic blocks, each entered with conservative waits; round 3, profiles/r03_*)
+//   AD      steps (taps) of lookahead of the weight-fragment ring
+//   MAXT    launch bound (768: 3 waves per SIMD / 168 VGPRs; 512: 2 waves per SIMD / 256 VGPRs for the P >= 3 shapes)
+#pragma once
+#include "common.h"
+#include "conv_epilogue.h"
+#include "layout.h"
+#include "split_arith.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace nnd {
+
+#ifndef NND_SPLIT_BSLOTS
+#define NND_SPLIT_BSLOTS 2  // register sets of the activation fragments (lookahead = sets - 1 units of NPROD MFMAs)
+#endif
+
+#ifdef NND_DBG_STAMPS
+// debug build only: per-workgroup phase timestamps (s_memrealtime, 100 MHz) for scripts/ablate_split.py; one copy per
+// instantiation unit (read back through nnd_debug_read_split_stamps_ns2 / _ns3)
+static __device__ unsigned long long g_split_stamps[4096 * 8];
+#define NND_SSTAMP(i)                                                                                  \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
+            if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();        \
+        }                                                                                              \
+    } while (0)
+// shader-clock stamps (s_memtime) in slots 5 / 6 next to the real-time stamps 1 / 2: in-kernel clock of the K loop
+#define NND_SCLOCK(i)                                                                                  \
+    do {                                                                                               \
+        if (threadIdx.x == 0) {                                                                        \
+            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
+            if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memtime();            \
+        }                                                                                              \
+    } while (0)
+#else
+#define NND_SSTAMP(i)
+#define NND_SCLOCK(i)
+#endif
+
+__host__ __device__ constexpr int split_pos_bytes(int NS) { return NS * 32 + 16; }
+__host__ __device__ constexpr int split_row_bytes(int PC, int NS) {
+    int rb = (PC * split_pos_bytes(NS) + 15) / 16;
+    while (rb % 16 != 8) ++rb;
+    return rb * 16;
+}
+
+// lane (0..31 of a half-wave) -> pixel index r*8 + c of the 4x8 sub-tile: the two lane groups that ds_read_b128 serves in
+// separate cycles get rows {0,1} and rows {2,3}
+__device__ __forceinline__ int lane_pixel(int l31) {
+    const bool g0 = (l31 < 4) || (l31 >= 12 && l31 < 16) || (l31 >= 20 && l31 < 28);
+    const int idx = g0 ? (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12)) : (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16));
+    return (g0 ? 0 : 16) + idx;
+}
+
+__host__ __device__ constexpr int split_gcd(int a, int b) { return b == 0 ? a : split_gcd(b, a % b); }
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void split_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void split_static_for(F&& f) {
+    split_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int KH, int KW, int NS, int P, int NU, bool FAST, int AD_, int MAXT>
+__global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
+    constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
+    constexpr int PR = 4 + KH - 1, PC = 8 + KW - 1, NPOS = PR * PC;
+    constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PC, NS), SUBB = PR * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    NND_SSTAMP(0);
+
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = a.wco, ks = a.ks;
+    const int cbi = wave % wco, kj = wave / wco;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int pxl = lane_pixel(l31), r = pxl >> 3, c = pxl & 7;
+    const int cb = blockIdx.y * wco + cbi;
+    const bool active = cb * 32 < a.Cout;
+    const int b = blockIdx.z;
+    const int Hin = a.Hin, Win = a.Win;
+    const long SP = a.ls.plane;
+    const int SCH = ks * 16;  // channels per super-chunk
+    // fp16x2: the power-of-two scale that undoes the range scaling of both operands (packed behind the bias), requested now
+    float oscale = 1.f;
+    if constexpr (NS == 2) oscale = a.bias[((a.Cout + 31) >> 5) << 5];
+
+    int ty0[P], tx0[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        const int t = blockIdx.x * P + pp;
+        const bool valid = t < a.npos;  // npos = number of sub-tiles of one image
+        ty0[pp] = valid ? (t / a.tiles_x) * 4 : (1 << 20);  // an absent sub-tile lies outside the image: staged as zeros, never stored
+        tx0[pp] = valid ? (t % a.tiles_x) * 8 : 0;
+    }
+
+    // ---- staging units of this thread: unit = (sub-tile, patch position, 8 consecutive channels of the super-chunk)
+    const int nunits = P * NPOS * 2 * ks;
+    int goff[NU], loff[NU], cho[NU];
+    bool inimg[NU], own[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = tid + i * nthreads;
+        own[i] = u < nunits;
+        const int pos = u % NPOS, rest = u / NPOS;
+        const int pp = rest % P, oct = rest / P;
+        const int pr = pos / PC, pc = pos - pr * PC;
+        int gy = 0, gx = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q == pp) {
+                gy = ty0[q] + pr - PH;
+                gx = tx0[q] + pc - PW;
+            }
+        inimg[i] = own[i] && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+        goff[i] = inimg[i] ? (int)pix_off(a.ls, gy, gx) : 0;
+        loff[i] = (oct >> 1) * (P * SUBB) + pp * SUBB + pr * ROWB + pc * PS + (oct & 1) * 16;
+        cho[i] = oct * 8;
+        if constexpr (FAST) goff[i] = inimg[i] ? cho[i] * (int)SP + goff[i] : 0;  // whole offset inside the super-chunk: the source is c4
+    }
+
+    f32x16 acc[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[pp][i] = 0.f;
+
+    const int nchunks = a.nchunks;  // 16-channel chunks
+    const int nsuper = (nchunks + ks - 1) / ks;
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpk) + (size_t)(active ? cb : 0) * nchunks * (NT * NS * 64) + lane;
+    float stage[NU][8];
+
+    auto chunk_src = [&](int K, const float*& src, int& climit) {
+        const int cbase = K * SCH;
+        if constexpr (FAST) {  // every super-chunk lies inside one source: a select, no branch; climit is not needed
+            const bool first = cbase < a.c0;
+            const float* s0 = a.src0 + b * a.bs0 + (long)cbase * SP;
+            const float* s1 = a.src1 + b * a.bs1 + (long)(cbase - a.c0) * SP;
+            src = first ? s0 : s1;
+            climit = SCH;
+        } else if (cbase < a.c0) {
+            src = a.src0 + b * a.bs0 + (long)cbase * SP;
+            climit = a.c0 - cbase;
+        } else {
+            const int cc = cbase - a.c0;
+            src = a.src1 + b * a.bs1 + (long)cc * SP;
+            climit = a.c1 - cc;
+        }
+    };
+    // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_unit.
+    const bool c4s = FAST || a.ls.ci == 4;  // 4-channel-interleaved source: a unit's 8 channels are two 16-B loads
+    auto load_unit = [&](int K, int i) {
+        const float* src;
+        int climit;
+        chunk_src(K, src, climit);
+        if constexpr (FAST) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (unsigned)(goff[i] + (inimg[i] ? 4 * g * (int)SP : 0)));
+                stage[i][4 * g] = t.x; stage[i][4 * g + 1] = t.y; stage[i][4 * g + 2] = t.z; stage[i][4 * g + 3] = t.w;
+            }
+        } else if (c4s) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int ci = cho[i] + 4 * g;  // multiple of 4: channel group ci/4 starts at ci*SP, like a planar channel
+                const float4 t = *reinterpret_cast<const float4*>(src + ((inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u));
+                stage[i][4 * g] = t.x; stage[i][4 * g + 1] = t.y; stage[i][4 * g + 2] = t.z; stage[i][4 * g + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = cho[i] + j;
+                stage[i][j] = src[(inimg[i] && ci < climit) ? (unsigned)(ci * (int)SP + goff[i]) : 0u];
+            }
+        }
+    };
+    auto store_unit = [&](int K, int i) {
+        const float* src;
+        int climit;
+        chunk_src(K, src, climit);
+        unsigned char* buf = lds_raw + (K & 1) * (ks * P * SUBB);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (inimg[i] && (FAST || cho[i] + j < climit)) ? stage[i][j] : 0.f;
+        uint4 pieces[NS];
+        split_pieces<NS>(v, pieces);
+        if (own[i]) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(buf + loff[i] + s * 32) = pieces[s];
+        }
+    };
+    auto load_x = [&](int K) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) load_unit(K, i);
+    };
+    auto store_x = [&](int K) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) store_unit(K, i);
+    };
+    auto a_ptr = [&](int K) {
+        int ch = K * ks + kj;
+        ch = ch < nchunks ? ch : 0;  // waves past the last chunk re-read chunk 0: harmless, their MFMAs are skipped
+        return wbase + (size_t)ch * (NT * NS * 64);
+    };
+    auto load_a = [&](uint4 (&dst)[NS], const uint4* wc, int t) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dst[s] = wc[(t * NS + s) * 64];
+    };
+
+    const int lane_base = kj * (P * SUBB) + r * ROWB + c * PS + h2 * 16;
+
+    // A fragments: a ring of AD + 1 register sets indexed by the global step g = K*NT + t; set g % NA holds step g, the
+    // loads of step g + AD are issued when step g starts (AD steps of MFMAs cover the L2 latency of the weight stream)
+    constexpr int AD = (AD_ < NT ? AD_ : NT), NA = AD + 1;
+    uint4 abuf[NA][NS];
+#pragma unroll
+    for (int g = 0; g < AD; ++g) load_a(abuf[g], a_ptr(0), g);
+    load_x(0);
+    store_x(0);
+    __syncthreads();
+    NND_SSTAMP(1);
+    NND_SCLOCK(5);
+
+    // `mine_c`: this wave's K slice exists in super-chunk K (always, in the FAST regime)
+    auto chunk_body = [&](int K, auto par_c, auto mine_c) {
+        constexpr int par = decltype(par_c)::value;
+        constexpr bool mine = decltype(mine_c)::value;
+        const bool more = (K + 1 < nsuper);
+#ifndef NND_SPLIT_NO_STAGE
+        if (more) load_x(K + 1);
+#endif
+        const uint4* wc = a_ptr(K);
+        const uint4* wn = a_ptr(more ? K + 1 : K);  // past the end: re-reads the last chunk, never used
+        const unsigned char* xb = lds_raw + (K & 1) * (ks * P * SUBB) + lane_base;
+        // B fragments rotate through NSLOT slots at (tap, sub-tile) granularity: unit u = t*P + pp lives in slot u % NSLOT and
+        // the reads of unit u + NSLOT - 1 are issued when unit u starts (its slot was freed by unit u - 1)
+        constexpr int NUNIT = NT * P, NSLOT = NND_SPLIT_BSLOTS;
+        uint4 bq[NSLOT][NS];
+        auto read_b = [&](int u, uint4 (&dst)[NS]) {
+            const int t = u / P, pp = u % P;
+            const int dy = t / KW, dx = t % KW;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + dy * ROWB + dx * PS + s * 32);
+        };
+#pragma unroll
+        for (int u = 0; u < NSLOT - 1 && u < NUNIT; ++u) read_b(u, bq[u]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint4(&ac)[NS] = abuf[(par + t) % NA];
+            uint4(&an)[NS] = abuf[(par + t + AD) % NA];
+#ifndef NND_SPLIT_NO_ALOAD
+            if (t + AD < NT) load_a(an, wc, t + AD);
+            else load_a(an, wn, t + AD - NT);
+#else
+            for (int s = 0; s < NS; ++s) an[s] = ac[s];
+#endif
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                const int u = t * P + pp;
+                if (u + NSLOT - 1 < NUNIT) read_b(u + NSLOT - 1, bq[(u + NSLOT - 1) % NSLOT]);
+#ifndef NND_SPLIT_NO_PIN
+                // keep the prefetches (weight fragments of step t + AD, activation fragments of the next unit) ABOVE the MFMAs
+                // they were written before: unpinned, the scheduler sinks every load down to its first use to save registers
+                // (global_load ... s_waitcnt vmcnt(0) ... v_mfma) and the ring hides nothing
+                if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef NND_SPLIT_NO_MFMA
+                if constexpr (mine)
+#else
+                if (mine && acc[0][0] == 123.f)
+#endif
+                    split_mfma_step<NS>(ac, bq[u % NSLOT], acc[pp]);  // small products first (split_arith.h)
+#ifndef NND_SPLIT_NO_PIN
+                if constexpr (FAST) __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+#ifndef NND_SPLIT_NO_STAGE
+        if (more) store_x(K + 1);
+#endif
+        __syncthreads();
+    };
+    auto chunk = [&](int K, auto par_c) {
+        if constexpr (FAST) {
+            chunk_body(K, par_c, std::true_type{});
+        } else {
+            if (K * ks + kj < nchunks) chunk_body(K, par_c, std::true_type{});
+            else chunk_body(K, par_c, std::false_type{});
+        }
+    };
+    // the ring phase of a chunk's first step, (K*NT) % NA, must be a compile-time constant: walk the chunks in periods
+    constexpr int STEP = NT % NA, PERIOD = NA / split_gcd(STEP, NA);
+    for (int K0 = 0; K0 < nsuper; K0 += PERIOD)
+        split_static_for<PERIOD>([&](auto j) {
+            constexpr int jj = decltype(j)::value;
+            if (jj == 0 || K0 + jj < nsuper) chunk(K0 + jj, std::integral_constant<int, (jj * STEP) % NA>{});
+        });
+
+    NND_SSTAMP(2);
+    NND_SCLOCK(6);
+    if constexpr (NS == 2) {  // exact: a power of two
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pp][i] *= oscale;
+    }
+    int ys[P], xs[P];
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) {
+        ys[pp] = ty0[pp] + r;
+        xs[pp] = tx0[pp] + c;
+    }
+    float* red_all = reinterpret_cast<float*>(lds_raw);
+    constexpr int TS = P * 1024;
+    // intra-workgroup split-K reduction through LDS (the patch buffers are free after the last barrier): every wave leaves
+    // its partial tile, slice kj then owns registers [kj*16/ks, (kj+1)*16/ks) of the summed tile for the epilogue
+    auto exchange = [&]() {
+        if (active) {
+            float* red = red_all + (size_t)(cbi * ks + kj) * TS + lane;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) red[pp * 1024 + reg * 64] = acc[pp][reg];
+        }
+        __syncthreads();
+    };
+    // c4 destination: NG = 4/ks register groups per sub-tile.  What the epilogue reads (per-pixel bias map, h, z) is requested
+    // BEFORE the exchange — the fragment registers are dead — and arrives while the partial sums cross LDS.
+    auto finish_c4 = [&](auto ng_c) {
+        constexpr int NG = decltype(ng_c)::value;  // == 4 / ks, ks = 2 or 4
+        const int q0 = kj * NG;
+        EpiOpsC4<P, NG> eo;
+#ifndef NND_SPLIT_NO_EPI
+        if (active) epi_c4_load<P, NG>(a, cb, b, h2, q0, ys, xs, eo);
+#endif
+        exchange();
+        if (!active) return;
+        float4 cacc[P][NG];
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* red = red_all + (size_t)(cbi * ks) * TS + pp * 1024 + (4 * (q0 + j) + i) * 64 + lane;
+                    float sum = red[0];
+#pragma unroll
+                    for (int sl = 1; sl < 4 / NG; ++sl) sum += red[(size_t)sl * TS];
+                    v[i] = sum;
+                }
+                cacc[pp][j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        NND_SSTAMP(3);
+#ifdef NND_SPLIT_NO_EPI
+        if (cacc[0][0].x != 123.456f) return;
+#endif
+        epi_c4_store<P, NG>(a, cacc, cb, b, h2, q0, eo);
+    };
+    if (a.ld.ci == 4) {
+        if (ks == 4) finish_c4(std::integral_constant<int, 1>{});
+        else if (ks == 2) finish_c4(std::integral_constant<int, 2>{});
+        else {  // no exchange to hide the loads behind
+            if (!active) return;
+            NND_SSTAMP(3);
+#ifdef NND_SPLIT_NO_EPI
+            if (acc[0][0] != 123.456f) return;
+#endif
+            conv_epilogue_c4<P>(a, acc, cb, b, h2, 0, 16, ys, xs);
+        }
+    } else {
+        if (ks > 1) exchange();
+        if (!active) return;
+        const int nreg = 16 / ks, reg0 = kj * nreg;
+        if (ks > 1) {
+            const float* red = red_all + (size_t)(cbi * ks) * TS + lane;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (reg < reg0 || reg >= reg0 + nreg) continue;
+                    float sum = red[pp * 1024 + reg * 64];
+                    for (int j = 1; j < ks; ++j) sum += red[(size_t)j * TS + pp * 1024 + reg * 64];
+                    acc[pp][reg] = sum;
+                }
+        }
+        NND_SSTAMP(3);
+#ifdef NND_SPLIT_NO_EPI
+        if (acc[0][0] != 123.456f) return;
+#endif
+        conv_epilogue_planar<P>(a, acc, cb, b, h2, reg0, nreg, ys, xs);
+    }
+#ifdef NND_DBG_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    NND_SSTAMP(4);
+}
+
+// --------------------------------------------------------------------------- host side shared by the instantiation units
+struct SplitCfg {
+    int ny, wco, ks, P, ntiles, tiles_x, nu;
+    bool fast;
+    size_t lds;
+};
+
+constexpr int SPLIT_MAX_WAVES = 12;
+
+template <int KH, int KW, int NS, int P, int NU, bool FAST, int AD, int MAXT>
+int launch_split_kernel(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+    auto kern = conv_split_kernel<KH, KW, NS, P, NU, FAST, AD, MAXT>;
+    if ((int)block.x > MAXT) {
+        set_error("conv_split: %u threads exceed the %d-thread bound of this instantiation", block.x, MAXT);
+        return NND_ERR_INVALID;
+    }
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+    return NND_OK;
+}
+
+// weight-ring depth per kernel shape in the FAST regime (steps of lookahead; NA = AD + 1 register sets of NS x 16 B):
+// 3x3: NA = 3 divides the 9 taps (one code copy of the chunk body); 1x5 / 5x1: NA = 5 divides the 5 taps for fp16x2 (40 VGPRs),
+// 3 sets for bf16x3 (the body is then instantiated for 3 ring phases); 1x1: 2 sets
+template <int KH, int KW, int NS>
+constexpr int split_fast_ad() {
+#ifdef NND_SPLIT_FAST_AD
+    return NND_SPLIT_FAST_AD;
+#else
+    return KH * KW == 9 ? 2 : (KH * KW == 5 ? (NS == 2 ? 4 : 2) : 1);
+#endif
+}
+
+// every instantiation of one (KH, KW, NS): generic (P = 2, NU 2 | 4, 768 threads) and FAST (P 2 | 3 | 4, NU 2 | 3 | 4)
+template <int KH, int KW, int NS>
+int launch_split_shape(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
+    constexpr int FAD = split_fast_ad<KH, KW, NS>();
+    if (!cfg.fast) {
+        if (cfg.P != 2) return NND_ERR_UNSUPPORTED;
+        if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, false, 1, 768>(a, grid, block, cfg.lds, stream);
+        return launch_split_kernel<KH, KW, NS, 2, 4, false, 1, 768>(a, grid, block, cfg.lds, stream);
+    }
+    if (cfg.P == 2) {
+        if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, FAD, 768>(a, grid, block, cfg.lds, stream);
+        return launch_split_kernel<KH, KW, NS, 2, 4, true, FAD, 768>(a, grid, block, cfg.lds, stream);
+    }
+    if constexpr (KH * KW > 1) {  // P = 3 / 4: the loop's 3x3 and 1x5 / 5x1 layers (2 waves per SIMD: 256 VGPRs)
+        if (cfg.P == 3) {
+            if (cfg.nu <= 3) return launch_split_kernel<KH, KW, NS, 3, 3, true, FAD, 512>(a, grid, block, cfg.lds, stream);
+            return NND_ERR_UNSUPPORTED;
+        }
+        if (cfg.P == 4) {
+            if (cfg.nu <= 3) return launch_split_kernel<KH, KW, NS, 4, 3, true, FAD, 512>(a, grid, block, cfg.lds, stream);
+            if (cfg.nu <= 4) return launch_split_kernel<KH, KW, NS, 4, 4, true, FAD, 512>(a, grid, block, cfg.lds, stream);
+            return NND_ERR_UNSUPPORTED;
+        }
+    }
+    return NND_ERR_UNSUPPORTED;
+}
+
+template <int NS>
+int launch_split_ns(const ConvArgs& a, const SplitCfg& cfg, int KH, int KW, dim3 grid, dim3 block, hipStream_t stream);
+
+#define NND_SPLIT_DEFINE_NS(NS)                                                                                                      \
+    template <>                                                                                                                      \
+    int launch_split_ns<NS>(const ConvArgs& a, const SplitCfg& cfg, int KH, int KW, dim3 grid, dim3 block, hipStream_t stream) {     \
+        if (KH == 3 && KW == 3) return launch_split_shape<3, 3, NS>(a, cfg, grid, block, stream);                                    \
+        if (KH == 1 && KW == 5) return launch_split_shape<1, 5, NS>(a, cfg, grid, block, stream);                                    \
+        if (KH == 5 && KW == 1) return launch_split_shape<5, 1, NS>(a, cfg, grid, block, stream);                                    \
+        if (KH == 1 && KW == 1) return launch_split_shape<1, 1, NS>(a, cfg, grid, block, stream);                                    \
+        return NND_ERR_UNSUPPORTED;                                                                                                  \
+    }
+
+}  // namespace nnd

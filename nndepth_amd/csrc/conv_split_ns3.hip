@@ -1,0 +1,11 @@
+// conv_split_kernel instantiations for arithmetic 3 ("bf16x3": 3 bf16 pieces, 6 products on v_mfma_f32_32x32x16_bf16).
+#include "conv_split_kernel.h"
+
+namespace nnd {
+NND_SPLIT_DEFINE_NS(3)
+#ifdef NND_DBG_STAMPS
+extern "C" int nnd_debug_read_split_stamps_ns3(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_split_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+}  // namespace nnd

@@ -28,8 +28,9 @@ static void load_switches() {
     s.debug_sync = on("NND_DEBUG_SYNC");
     s.split_mask = ~0u;
     if (const char* e = getenv("NND_SPLIT_MASK")) s.split_mask = (unsigned)strtoul(e, nullptr, 0);
-    s.split_ny = s.split_ks = -1;
-    if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d", &s.split_ny, &s.split_ks);
+    s.split_ny = s.split_ks = s.split_p = -1;
+    if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d,%d", &s.split_ny, &s.split_ks, &s.split_p);
+    s.split_no_fast = on("NND_SPLIT_NO_FAST");
     s.conv_p = s.conv_ks = s.conv_wco = -1;
     if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &s.conv_p, &s.conv_ks, &s.conv_wco);
     if (const char* e = getenv("NND_CONV_P")) s.conv_p = atoi(e);

@@ -147,7 +147,13 @@ def igev(report):
         captured["init"] = orig_reg(dist, width)
         return captured["init"]
 
-    model.convex_upsample, model.regress_disparity = spy, spy_reg
+    orig_sq = model.cv_squeezer.forward
+
+    def spy_sq(x):
+        captured["logits"] = orig_sq(x)
+        return captured["logits"]
+
+    model.convex_upsample, model.regress_disparity, model.cv_squeezer.forward = spy, spy_reg, spy_sq
     with torch.no_grad():
         t0 = time.time()
         out = model(f1, f2)
@@ -163,6 +169,12 @@ def igev(report):
     report["igev/coords range at the 1/4 map (it 1, 12, 32), map width"] = tuple(x for r in rng for x in r) + (float(W4),)
     report["igev/init disparity range"] = (captured["init"].min().item(), captured["init"].max().item())
     report["igev/ref self-noise 1thr vs 8thr (it 1,4,12,32)"] = tuple((out1[i - 1]["up_disp"] - out[i - 1]["up_disp"]).abs().max().item() for i in KEEP)
+    # how far the reference's own fp32 soft-argmin (softmax over 240 candidates, then -sum d * p_d) is from the float64 value of
+    # the same expression on the same logits: the accuracy to which the initial disparity is DEFINED
+    lg = captured["logits"].squeeze(1).double()
+    init64 = -(torch.arange(lg.shape[1], dtype=torch.float64).view(1, -1, 1, 1) * torch.softmax(lg, 1)).sum(1, keepdim=True)
+    init_err64 = (captured["init"].double() - init64).abs().max().item()
+    report["igev/reference fp32 soft-argmin init vs float64 of the same logits (max-abs)"] = (init_err64,)
     noise_up = tuple((out1[i - 1]["up_disp"] - out[i - 1]["up_disp"]).abs().max().item() for i in KEEP)
     noise_low = tuple((lows1[i - 1] - lows8[i - 1]).abs().max().item() for i in KEEP)
     report["igev/ref self-noise of the 1/4-resolution coordinates (it 1,4,12,32)"] = noise_low
@@ -171,7 +183,7 @@ def igev(report):
     # 1-thread vs 8-thread outputs differ by more than 1e-4 at full resolution; the self-noise is stored next to the outputs
     np.savez_compressed(os.path.join(GOLD, "forward_igev_tartanair.npz"), up_disp_it32=_np(out[-1]["up_disp"]).astype(np.float32),
                         low_coords=np.stack([_np(lows8[i - 1]) for i in KEEP]), low_iters=np.array(KEEP), init=_np(captured["init"]),
-                        ref_self_noise_up=np.array(noise_up), ref_self_noise_low=np.array(noise_low))
+                        ref_self_noise_up=np.array(noise_up), ref_self_noise_low=np.array(noise_low), ref_init_err_vs_f64=np.array(init_err64))
 
 
 def main():

@@ -1,6 +1,7 @@
-"""Workgroup-shape sweep of conv_split.hip: launch time of every bf16x3 loop conv for forced (ny, ks) = (output-channel groups
-across workgroups, intra-workgroup split-K) via NND_SPLIT_CFG, next to the picker's own choice.
-    python scripts/sweep_split.py H W [B]        (on the GPU box; one subprocess per configuration)"""
+"""Workgroup-shape sweep of conv_split: launch time of every loop conv in a split arithmetic for forced (ny, ks, P) = (output-
+channel groups across workgroups, intra-workgroup split-K, sub-tiles per wave) via NND_SPLIT_CFG, next to the picker's own
+choice and to the generic (pre-round-3) kernel (NND_SPLIT_NO_FAST).
+    python scripts/sweep_split.py H W [B] [arithmetic]       (on the GPU box; one subprocess per configuration)"""
 import os
 import subprocess
 import sys
@@ -13,7 +14,7 @@ import torch
 from nndepth_amd import weightgen
 from nndepth_amd.blocks import BasicUpdateBlock
 H, W, B = int(os.environ["AB_H"]), int(os.environ["AB_W"]), int(os.environ["AB_B"])
-ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic="bf16x3")
+ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic=os.environ.get("AB_ARITH", "fp16x2"))
 weightgen.fill_module_(ub, "update_block.")
 ub = ub.to("cuda:0"); eng = ub.sync_engine("cuda:0")
 ws = eng.workspace(B, H, W, "cuda:0"); ws.normal_()
@@ -32,10 +33,14 @@ print(" ".join(out), flush=True)
 if __name__ == "__main__":
     H, W = int(sys.argv[1]), int(sys.argv[2])
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    print(f"{H}x{W} batch {B}; columns: convc2 convf2 conv zr1 q1 zr2 q2 fhm   (us per launch)")
-    for cfg in [None, "1,1", "1,2", "1,4", "2,1", "2,2", "2,4", "3,1", "3,2", "3,4", "4,1", "4,2", "4,4", "6,1", "6,2", "6,4"]:
-        env = dict(os.environ, AB_H=str(H), AB_W=str(W), AB_B=str(B))
-        if cfg:
+    arith = sys.argv[4] if len(sys.argv) > 4 else "fp16x2"
+    print(f"{H}x{W} batch {B} {arith}; columns: convc2 convf2 conv zr1 q1 zr2 q2 fhm   (us per launch); rows: ny,ks,P")
+    cfgs = [None, "generic"] + [f"{ny},{ks},{p}" for p in (2, 3, 4) for ny in (1, 2, 3, 4, 6) for ks in (1, 2, 4)]
+    for cfg in cfgs:
+        env = dict(os.environ, AB_H=str(H), AB_W=str(W), AB_B=str(B), AB_ARITH=arith)
+        if cfg == "generic":
+            env["NND_SPLIT_NO_FAST"] = "1"
+        elif cfg:
             env["NND_SPLIT_CFG"] = cfg
         r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.strip() and "amdgpu" not in l]
