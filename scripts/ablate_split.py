@@ -1,5 +1,5 @@
 """Ablation of conv_split.hip (timing-only builds under scripts/ablate/, made by scripts/build_ablate.sh): per-conv launch time
-of the bf16x3 loop convs at 68x120 for each build, plus the phase stamps of the STAMPS build.
+of the loop convs (AB_ARITH = fp16x2 | bf16x3) at 68x120 for each build, plus the phase stamps of the STAMPS build.
     python scripts/ablate_split.py            (on the GPU box; spawns one subprocess per library)"""
 import os
 import subprocess
@@ -31,7 +31,8 @@ for i, nm in enumerate(names):
     if stamps:
         eng.profile_conv(i, 1, H, W, 1, "cuda:0")
         torch.cuda.synchronize()
-        assert raw.nnd_debug_read_split_stamps(buf, 4096 * 8) == 0
+        ns = {"fp16x2": 2, "bf16x3": 3}[os.environ.get("AB_ARITH", "fp16x2")]
+        assert getattr(raw, f"nnd_debug_read_split_stamps_ns{ns}")(buf, 4096 * 8) == 0
         full = np.array(buf[:], dtype=np.int64).reshape(4096, 8)
         keep = (full[:, 0] > 0) & (full[:, 4] >= full[:, 0])
         a = full[keep][:, :5]
