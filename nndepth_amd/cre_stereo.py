@@ -106,14 +106,26 @@ class LocalFeatureTransformer(nn.Module):
         return self._layer_step(lambda i, a, b: self._engines[i].forward(a.float(), b.float()), map0, map1)
 
 
+_PE_CACHE = {}
+
+
 def position_encoding_sine(d_model: int, h: int, w: int, device) -> torch.Tensor:
-    """(1, d_model, h, w) table of nndepth/blocks/pos_enc.py:22-42 incl. its `/ d_model // 2` precedence quirk."""
+    """(1, d_model, h, w) table of nndepth/blocks/pos_enc.py:22-42 incl. its `/ d_model // 2` precedence quirk.  A constant of
+    (d_model, h, w): built on the host once per shape and device and kept resident (the reference registers it as a buffer) —
+    rebuilding it per forward cost a host-side table computation plus a synchronous 2 MB upload per pair."""
+    key = (d_model, h, w, str(device))
+    if key not in _PE_CACHE:
+        _PE_CACHE[key] = _position_encoding_sine_host(d_model, h, w).to(device)
+    return _PE_CACHE[key]
+
+
+def _position_encoding_sine_host(d_model: int, h: int, w: int) -> torch.Tensor:
     y = torch.ones(h, w).cumsum(0).unsqueeze(0)
     x = torch.ones(h, w).cumsum(1).unsqueeze(0)
     div = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / d_model // 2))[:, None, None]
     pe = torch.zeros(d_model, h, w)
     pe[0::4], pe[1::4], pe[2::4], pe[3::4] = torch.sin(x * div), torch.cos(x * div), torch.sin(y * div), torch.cos(y * div)
-    return pe[None].to(device)
+    return pe[None]
 
 
 # ------------------------------------------------------------------ the model

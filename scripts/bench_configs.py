@@ -1,8 +1,8 @@
-"""Per-GPU work of BASELINE.json configs 3, 4 and 5 on one MI355X, in both arithmetics (exact fp32 MFMA / bf16x3 split):
+"""Per-GPU work of BASELINE.json configs 3, 4 and 5 on one MI355X, per arithmetic (exact fp32 MFMA / bf16x3 / fp16x2 split):
     config 3  IGEV hot path at 544x960 (136x240 at 1/4): volume, regulariser, init, 32-iteration loop, batch 1 and 8
     config 4  RAFT-Stereo, 8 x 384x1248 (KITTI padded), 32 iterations
     config 5  CREStereo 1080x1920, 20 iterations: single cascade and the 2-stage harness
-    python scripts/bench_configs.py            (on the GPU box)"""
+    python scripts/bench_configs.py [fp32,bf16x3,fp16x2]           (on the GPU box)"""
 import os
 import sys
 import time
@@ -69,6 +69,6 @@ if __name__ == "__main__":
         main()
     else:  # one process per (arithmetic, configuration): every measurement starts from a fresh allocator and library state
         import subprocess
-        for ar in ("fp32", "bf16x3"):
+        for ar in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("fp32", "bf16x3", "fp16x2")):
             for which in ("kitti", "cre", "igev1", "igev8"):
                 subprocess.run([sys.executable, os.path.abspath(__file__), ar, which], check=False)
