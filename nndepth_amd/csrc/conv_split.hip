@@ -117,7 +117,7 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
                     if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
                     if (c1 > 0 && c0 % (ks * 16) != 0) continue;
                     const bool fast = fast_ok && L.nchunks % ks == 0;
-                    if (P > 2 && (!fast || waves > 8 || L.KH * L.KW == 1)) continue;  // P = 3 / 4: FAST kernels with <= 512 threads
+                    if (P > 2) continue;  // P = 3 / 4 are not instantiated (see launch_split_shape)
                     const int nu = cdiv(P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread
                     if (nu > 4 || (P == 3 && nu > 3)) continue;
                     size_t lds = (size_t)2 * ks * P * subb;
@@ -168,9 +168,11 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     NND_REQUIRE(L.CI_T == 16 && L.nchunks * 16 == L.Cin, "conv_split: layer was not planned for 16-channel chunks");
     NND_REQUIRE((long)(L.Cin + 64) * tiled_plane(H, W) < (1L << 31), "conv_split: plane offsets exceed 32 bits");
     SplitCfg cfg;
-    // FAST regime: both sources c4 tile-major (the refinement loops' own tensors); per candidate shape the picker also requires
-    // full super-chunks that never straddle the two sources.  NND_SPLIT_NO_FAST (diagnostic) keeps the generic kernel.
-    const bool fast_ok = io.src_c4 && io.src_tiled && !switches().split_no_fast;
+    // FAST regime: any source layout the kernel addresses as plane + pixel offset — c4 tile-major (the refinement loops' own
+    // tensors), planar tile-major (the encoder's) or NCHW (C-ABI tensors: cnet_proj reads the feature map, the Conv3d layers
+    // their depth-major volumes); per candidate shape the picker also requires full super-chunks that never straddle the two
+    // sources.  NND_SPLIT_NO_FAST (diagnostic) keeps the generic kernel.
+    const bool fast_ok = !switches().split_no_fast;
     NND_REQUIRE(pick_split(L, io.src0.C, io.src1.C, B, H, W, fast_ok, &cfg), "conv_split: no configuration for %dx%d Cin=%d (%d+%d)", L.KH,
                 L.KW, L.Cin, io.src0.C, io.src1.C);
     ConvArgs a;

@@ -8,8 +8,9 @@
 //   NS      pieces per fp32 operand (3: bf16, 2: range-scaled fp16)
 //   P       4x8-pixel sub-tiles per wave (each weight fragment feeds P MFMA groups): 2, 3 or 4
 //   NU      staging units per thread (unit = patch position x 8 channels)
-//   FAST    the regime of the refinement loops' own tensors, decided by the host: both sources in the 4-channel-interleaved
-//           tile-major layout, every super-chunk of ks*16 channels full and inside one source.  Then nothing in the K loop is
+//   FAST    decided by the host: every super-chunk of ks*16 channels full and inside one source (SRC4: sources tile-major with
+//           4 channels interleaved — the refinement loops' tensors; else planar, tile-major or NCHW — the encoder's, the C-ABI's).
+//           Then nothing in the K loop is
 //           a run-time branch — the walk over (tap, sub-tile) is straight-line code whose waits the compiler can count exactly
 //           (round 2's kernel guarded every MFMA group with a wave-uniform `mine` test and chose the load form per unit at run
 //           time: the walk was cut into ~20 basic blocks, each entered with conservative waits; round 3, profiles/r03_*)
@@ -80,7 +81,7 @@ __device__ __forceinline__ void split_static_for(F&& f) {
     split_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <int KH, int KW, int NS, int P, int NU, bool FAST, int AD_, int MAXT>
+template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD_, int MAXT>
 __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
     constexpr int PR = 4 + KH - 1, PC = 8 + KW - 1, NPOS = PR * PC;
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
         goff[i] = inimg[i] ? (int)pix_off(a.ls, gy, gx) : 0;
         loff[i] = (oct >> 1) * (P * SUBB) + pp * SUBB + pr * ROWB + pc * PS + (oct & 1) * 16;
         cho[i] = oct * 8;
-        if constexpr (FAST) goff[i] = inimg[i] ? cho[i] * (int)SP + goff[i] : 0;  // whole offset inside the super-chunk: the source is c4
+        if constexpr (FAST) goff[i] = inimg[i] ? cho[i] * (int)SP + goff[i] : 0;  // whole offset inside the super-chunk
     }
 
     f32x16 acc[P];
@@ -167,17 +168,21 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
         }
     };
     // unconditional loads with clamped addresses (element 0 when masked); the zero fill is a select in store_unit.
-    const bool c4s = FAST || a.ls.ci == 4;  // 4-channel-interleaved source: a unit's 8 channels are two 16-B loads
+    const bool c4s = FAST ? SRC4 : a.ls.ci == 4;  // 4-channel-interleaved source: a unit's 8 channels are two 16-B loads
     auto load_unit = [&](int K, int i) {
         const float* src;
         int climit;
         chunk_src(K, src, climit);
-        if constexpr (FAST) {
+        if constexpr (FAST && SRC4) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float4 t = *reinterpret_cast<const float4*>(src + (unsigned)(goff[i] + (inimg[i] ? 4 * g * (int)SP : 0)));
                 stage[i][4 * g] = t.x; stage[i][4 * g + 1] = t.y; stage[i][4 * g + 2] = t.z; stage[i][4 * g + 3] = t.w;
             }
+        } else if constexpr (FAST) {  // planar tile-major source: 8 channel planes, one 4-B load each
+            const int step = inimg[i] ? (int)SP : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage[i][j] = src[(unsigned)(goff[i] + j * step)];
         } else if (c4s) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -425,9 +430,9 @@ struct SplitCfg {
 
 constexpr int SPLIT_MAX_WAVES = 12;
 
-template <int KH, int KW, int NS, int P, int NU, bool FAST, int AD, int MAXT>
+template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD, int MAXT>
 int launch_split_kernel(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    auto kern = conv_split_kernel<KH, KW, NS, P, NU, FAST, AD, MAXT>;
+    auto kern = conv_split_kernel<KH, KW, NS, P, NU, FAST, SRC4, AD, MAXT>;
     if ((int)block.x > MAXT) {
         set_error("conv_split: %u threads exceed the %d-thread bound of this instantiation", block.x, MAXT);
         return NND_ERR_INVALID;
@@ -452,31 +457,23 @@ constexpr int split_fast_ad() {
 #endif
 }
 
-// every instantiation of one (KH, KW, NS): generic (P = 2, NU 2 | 4, 768 threads) and FAST (P 2 | 3 | 4, NU 2 | 3 | 4)
+// every instantiation of one (KH, KW, NS): generic and FAST (c4 / planar tile-major sources), P = 2, NU 2 | 4, 768 threads.
+// (P = 3 / 4 with 8 waves were measured at 68x120 and lose to P = 2 with 12 waves on every layer — profiles/r03_split_shape_sweep_68x120.txt
+//  — so they are not instantiated; the kernel template itself stays general in P.)
 template <int KH, int KW, int NS>
 int launch_split_shape(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
     constexpr int FAD = split_fast_ad<KH, KW, NS>();
+    if (cfg.P != 2) return NND_ERR_UNSUPPORTED;
     if (!cfg.fast) {
-        if (cfg.P != 2) return NND_ERR_UNSUPPORTED;
-        if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, false, 1, 768>(a, grid, block, cfg.lds, stream);
-        return launch_split_kernel<KH, KW, NS, 2, 4, false, 1, 768>(a, grid, block, cfg.lds, stream);
+        if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, false, false, 1, 768>(a, grid, block, cfg.lds, stream);
+        return launch_split_kernel<KH, KW, NS, 2, 4, false, false, 1, 768>(a, grid, block, cfg.lds, stream);
     }
-    if (cfg.P == 2) {
-        if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, FAD, 768>(a, grid, block, cfg.lds, stream);
-        return launch_split_kernel<KH, KW, NS, 2, 4, true, FAD, 768>(a, grid, block, cfg.lds, stream);
+    if (a.ls.ci == 4) {
+        if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, true, FAD, 768>(a, grid, block, cfg.lds, stream);
+        return launch_split_kernel<KH, KW, NS, 2, 4, true, true, FAD, 768>(a, grid, block, cfg.lds, stream);
     }
-    if constexpr (KH * KW > 1) {  // P = 3 / 4: the loop's 3x3 and 1x5 / 5x1 layers (2 waves per SIMD: 256 VGPRs)
-        if (cfg.P == 3) {
-            if (cfg.nu <= 3) return launch_split_kernel<KH, KW, NS, 3, 3, true, FAD, 512>(a, grid, block, cfg.lds, stream);
-            return NND_ERR_UNSUPPORTED;
-        }
-        if (cfg.P == 4) {
-            if (cfg.nu <= 3) return launch_split_kernel<KH, KW, NS, 4, 3, true, FAD, 512>(a, grid, block, cfg.lds, stream);
-            if (cfg.nu <= 4) return launch_split_kernel<KH, KW, NS, 4, 4, true, FAD, 512>(a, grid, block, cfg.lds, stream);
-            return NND_ERR_UNSUPPORTED;
-        }
-    }
-    return NND_ERR_UNSUPPORTED;
+    if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, false, FAD, 768>(a, grid, block, cfg.lds, stream);
+    return launch_split_kernel<KH, KW, NS, 2, 4, true, false, FAD, 768>(a, grid, block, cfg.lds, stream);
 }
 
 template <int NS>
