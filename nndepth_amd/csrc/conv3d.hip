@@ -201,9 +201,16 @@ int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
     return t1 + tj + tt;  // [plain layer | J-slice grouped layer | thin-layer VALU kernel]
 }
 
-// the thin (Cout 8 / 16) layers run on thin3d.hip unless NND_NO_THIN3D is set (diagnostic: the MFMA formulations above)
+// Which formulation a thin (Cout 8 / 16) layer takes.  Exact arithmetic: the direct VALU kernel of thin3d.hip on all of them
+// (NND_NO_THIN3D, diagnostic: the MFMA formulations above).  Split arithmetics: the J-slice grouped layer on the 16-bit MFMA
+// (conv_split, FAST regime on the depth-major slabs) wherever it is the faster one — measured per layer at 544x960 with fp16x2
+// (profiles/r03_igev_regulariser_layers_*.txt, us thin / MFMA): conv1.1 16->16 288 / 198, conv2_up 32->16 540 / 268, proj_2
+// 32->16 547 / 277, conv1_up 16->8 1020 / 876, but final_conv 8->8 533 / 600 (K = 6 x 8 x 9 is too short for the workgroup's
+// fixed phases) and the stride-2 layers 330 / 1041 (no stride-2 split kernel): those two kinds stay on the VALU kernel.
 static bool use_thin(const nnd_conv3d_desc* d) {
-    return !switches().no_thin3d && thin3d_supported(d->Cout, d->stride);
+    if (switches().no_thin3d || !thin3d_supported(d->Cout, d->stride)) return false;
+    if (d->arithmetic == 0 || d->stride != 1) return true;
+    return d->Cin0 + d->Cin1 <= 8;
 }
 
 // 2-D weights of the J-slice grouped layer: (J*Cout, (J+2)*Ct, 3, 3) with [window of input 0: slice-major, ci][window of input 1]

@@ -171,8 +171,9 @@ class IGEVStereoBase(nn.Module):
         self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, context_dim=context_dim, flow_channel=1,
                                              cor_planes=corr_levels * (2 * corr_radius + 1) * cv_groups * 2, spatial_scale=4,
                                              arithmetic=arithmetic)
-        self.cv_regularizer = self._init_cost_volume_filter()  # its own `.arithmetic` stays "fp32": the thin Conv3d layers
-                                                               # gain nothing from the split kernel (profiles/r02_igev_regulariser_*)
+        self.cv_regularizer = self._init_cost_volume_filter()
+        if hasattr(self.cv_regularizer, "arithmetic"):  # the HIP regulariser follows the model's arithmetic (5.4 -> 4.3 ms per
+            self.cv_regularizer.arithmetic = arithmetic  # 544x960 sample with fp16x2: profiles/r03_igev_regulariser_layers_*.txt)
         self.corr_fn = GeometryAwareCostVolume
         self.cv_squeezer = nn.Conv3d(cv_groups, 1, 3, 1, 1)
         self.tracing, self.include_preprocessing = tracing, include_preprocessing
