@@ -83,6 +83,9 @@ def main():
                          "fp32 operands carried as 2 range-scaled fp16 pieces, 3 products on v_mfma_f32_32x32x16_f16; bf16x3 = 3 bf16 "
                          "pieces, 6 products on v_mfma_f32_32x32x16_bf16; fp32 accumulate in both (csrc/conv_split.hip, parity-gated by "
                          "tests/test_gpu_split.py + tests/test_gpu_realdata.py); fp32 = exact fp32 MFMA (csrc/conv_mfma.hip)")
+    ap.add_argument("--launch", default="direct", choices=["direct", "graph"],
+                    help="direct = every kernel of a step enqueued by the C-ABI calls (default); graph = the whole forward captured once "
+                         "into a HIP graph and replayed (nndepth_amd/graph.py: one host-side launch per pair, same kernels, bit-identical)")
     ap.add_argument("--config", default="raft544", choices=["raft544", "kitti64", "cre8"],
                     help="raft544 = BASELINE.json configs[1] (the headline, default); kitti64 = configs[3]: 64 KITTI-size pairs "
                          "sharded over the ranks; cre8 = configs[4]: 8 CREStereo 1080x1920 pairs, 2-stage cascade, sharded")
@@ -114,8 +117,13 @@ def main():
     f1, f2 = weightgen.synthetic_frames(100 + rank, 1, H_IMG, W_IMG)  # a different pair per rank
     f1, f2 = f1.to(dev), f2.to(dev)
 
+    fwd = model
+    if args.launch == "graph":
+        from nndepth_amd.graph import GraphedForward
+        fwd = GraphedForward(model)
+
     def step():
-        out = model(f1, f2)
+        out = fwd(f1, f2)
         final = out[-1]["up_disp"]
         if world > 1:
             final = parallel.gather_disparity(final)
@@ -160,7 +168,7 @@ def main():
         "dtype": DTYPE[args.arithmetic],
         "data": "synthetic",
         "config": {"workload": "RAFT-Stereo base (ctx 64), 544x960, 32 iters, batch 1 per GPU, all 32 up_disp emitted",
-                   "pairs_per_step": world, "parallelism": f"batch-parallel x{world}" if world > 1 else "single",
+                   "pairs_per_step": world, "parallelism": f"batch-parallel x{world}" if world > 1 else "single", "launch": args.launch,
                    "arithmetic": ARITH_NOTE[args.arithmetic]},
     }
     if args.arithmetic != "fp32" and rank == 0 and world == 1:

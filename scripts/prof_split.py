@@ -1,5 +1,5 @@
-"""Stand-alone launch time of every conv of the RAFT-Stereo loop at 68x120 in both arithmetics (exact fp32 MFMA vs bf16x3
-split MFMA), hipEvents on the launch stream (nnd_profile_conv), then the whole 544x960 / 32-iteration forward.
+"""Stand-alone launch time of every conv of the RAFT-Stereo loop at 68x120 in the three arithmetics (exact fp32 MFMA, bf16x3 and
+fp16x2 split MFMA), hipEvents on the launch stream (nnd_profile_conv), then the whole 544x960 / 32-iteration forward.
     python scripts/prof_split.py [H W]          (on the GPU box)"""
 import os
 import sys
@@ -12,8 +12,9 @@ from nndepth_amd.raft_stereo import BaseRAFTStereo  # noqa: E402
 
 dev = "cuda:0"
 Hf, Wf = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (68, 120)
+ARITHS = ("fp32", "bf16x3", "fp16x2")
 models = {}
-for ar in ("fp32", "bf16x3"):
+for ar in ARITHS:
     m = BaseRAFTStereo(iters=32, context_dim=64, arithmetic=ar)
     weightgen.fill_module_(m)
     models[ar] = m.to(dev).eval()
@@ -23,14 +24,13 @@ for ar, m in models.items():
     for i, nm in enumerate(eng.conv_names()):
         ms, fl = eng.profile_conv(i, 1, Hf, Wf, 30, dev)
         rows.setdefault(nm, {})[ar] = (ms * 1e3, fl / 1e9)
-print(f"{'conv':34s} {'GFLOP':>7s} {'fp32 us':>9s} {'TF':>6s} {'bf16x3 us':>10s} {'TF(alg)':>8s} {'speedup':>8s}")
-tot = {"fp32": 0.0, "bf16x3": 0.0}
+print(f"{'conv':34s} {'GFLOP':>7s} " + " ".join(f"{ar + ' us':>10s} {'TF(alg)':>8s}" for ar in ARITHS))
+tot = {ar: 0.0 for ar in ARITHS}
 for nm, r in rows.items():
-    a, b = r["fp32"], r["bf16x3"]
-    tot["fp32"] += a[0]
-    tot["bf16x3"] += b[0]
-    print(f"{nm:34s} {a[1]:7.2f} {a[0]:9.1f} {a[1] / a[0] * 1e3:6.1f} {b[0]:10.1f} {b[1] / b[0] * 1e3:8.1f} {a[0] / b[0]:8.2f}")
-print(f"{'sum':34s} {'':7s} {tot['fp32']:9.1f} {'':6s} {tot['bf16x3']:10.1f} {'':8s} {tot['fp32'] / tot['bf16x3']:8.2f}")
+    for ar in ARITHS:
+        tot[ar] += r[ar][0]
+    print(f"{nm:34s} {r['fp32'][1]:7.2f} " + " ".join(f"{r[ar][0]:10.1f} {r[ar][1] / r[ar][0] * 1e3:8.1f}" for ar in ARITHS))
+print(f"{'sum':34s} {'':7s} " + " ".join(f"{tot[ar]:10.1f} {'':8s}" for ar in ARITHS))
 f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(100, 1, Hf * 8, Wf * 8))
 outs = {}
 for ar, m in models.items():
@@ -44,4 +44,5 @@ for ar, m in models.items():
     dt = (time.perf_counter() - t0) / 20
     outs[ar] = out[-1]["up_disp"]
     print(f"forward {Hf * 8}x{Wf * 8} / 32 iters, {ar}: {dt * 1e3:.2f} ms = {1 / dt:.1f} pairs/s")
-print(f"max-abs up_disp bf16x3 vs fp32 path: {(outs['fp32'] - outs['bf16x3']).abs().max().item():.2e}")
+for ar in ARITHS[1:]:
+    print(f"max-abs up_disp {ar} vs fp32 path: {(outs['fp32'] - outs[ar]).abs().max().item():.2e}")
