@@ -135,7 +135,7 @@ void pack_conv(const ConvLayer& L, int nparts, const float* const* w, const floa
 
 // conv_split.hip: the same convolution with fp32 operands carried as split bf16 pieces on the 16-bit MFMA (L.arith != 0);
 // launch_conv / pack_conv dispatch to these.
-bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith);
+bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith, int Cout = 0);  // Cout matters for stride 2 only
 int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W, hipStream_t stream);
 // motion encoder flow branch in one launch (conv_split.hip): f2 = convf2's split-packed layer, w7t = convf1's weights tap-major
 // ([fc*49][128]), b7 its bias

@@ -35,8 +35,8 @@ static int conv3d_layer(const nnd_conv3d_desc* d, int J, ConvLayer* L, int64_t* 
     l.Cin = (J + 2) * (d->Cin0 + d->Cin1);
     l.Cout = J * d->Cout;
     l.stride = d->stride;
-    // arithmetic 3: stride-1 layers whose plane count is a multiple of 16 on the split-bf16 MFMA kernel (conv_split.hip)
-    l.arith = (d->arithmetic != 0 && conv_split_supported(3, 3, l.Cin, d->stride, d->arithmetic) &&
+    // split arithmetics: layers (stride 1 and 2) whose plane count is a multiple of 16 on the 16-bit MFMA kernel (conv_split)
+    l.arith = (d->arithmetic != 0 && conv_split_supported(3, 3, l.Cin, d->stride, d->arithmetic, l.Cout) &&
                (d->Cin1 == 0 || ((J + 2) * d->Cin0) % 16 == 0)) ? d->arithmetic : 0;
     l.CI_T = 16;  // windows of 3*Cin planes: 24, 48, 96, 192 -> 16-channel chunks keep the two sources chunk-aligned
     NND_REQUIRE(d->Cin1 == 0 || ((J + 2) * d->Cin0) % l.CI_T == 0, "conv3d: first input of a concat needs (J+2)*Cin0 %% 16 == 0 (Cin0 = %d)", d->Cin0);

@@ -68,9 +68,13 @@ float bf16_to_f(uint16_t h) {
 // a output-channel blocks x P sub-tiles moves a x (weights of a block) + P x (patch of a sub-tile) through its CU's L2 path —
 // at 68x120 the 12-wave shapes of round 2 (3 x 2, 4 x 2, 6 x 2 blocks x sub-tiles) become 2 x 3, 2 x 4, 4 x 3.
 bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fast_ok, SplitCfg* out) {
-    const int NS = L.arith;
-    const int PR = 4 + L.KH - 1, PC = 8 + L.KW - 1;
-    const size_t subb = (size_t)PR * split_row_bytes(PC, NS);
+    const int NS = L.arith, STR = L.stride;
+    // patch geometry of one sub-tile (SplitGeom in conv_split_kernel.h): positions staged and bytes in LDS
+    const int PRI = 3 * STR + L.KH, PCI = 7 * STR + L.KW, k11 = L.KH * L.KW == 1;
+    const int nph = STR == 1 ? 1 : (k11 ? 1 : 4);
+    const int prp = STR == 1 ? PRI : (L.KH == 1 ? 4 : (PRI + 1) / 2), pcp = STR == 1 ? PCI : (L.KW == 1 ? 8 : (PCI + 1) / 2);
+    const int npos = (STR == 2 && k11) ? 32 : PRI * PCI;
+    const size_t subb = (size_t)nph * prp * split_row_bytes(pcp, NS);
     const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
     int force_ny = switches().split_ny, force_ks = switches().split_ks, force_p = switches().split_p;
     const bool forced = force_ny > 0 || force_ks > 0 || force_p > 0;
@@ -118,7 +122,8 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
                     if (c1 > 0 && c0 % (ks * 16) != 0) continue;
                     const bool fast = fast_ok && L.nchunks % ks == 0;
                     if (P > 2) continue;  // P = 3 / 4 are not instantiated (see launch_split_shape)
-                    const int nu = cdiv(P * PR * PC * 2 * ks, 64 * waves);  // staging units per thread
+                    if (STR == 2 && !fast) continue;  // the stride-2 kernels exist in the FAST regime only
+                    const int nu = cdiv(P * npos * 2 * ks, 64 * waves);  // staging units per thread
                     if (nu > 4 || (P == 3 && nu > 3)) continue;
                     size_t lds = (size_t)2 * ks * P * subb;
                     const size_t red = ks > 1 ? (size_t)waves * P * 4096 : 0;
@@ -137,7 +142,7 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
                     if (nu > 2 && P == 2) t *= 1.2;                // register-heavy staging variant
                     if (t < best) {
                         best = t;
-                        *out = {ny, wco, ks, P, ntiles, tiles_x, P == 2 ? (nu <= 2 ? 2 : 4) : (nu <= 3 ? 3 : 4), fast, lds};
+                        *out = {ny, wco, ks, P, ntiles, tiles_x, P == 2 ? (nu <= 2 ? 2 : 4) : (nu <= 3 ? 3 : 4), fast, lds, STR};
                         found = true;
                     }
                 }
@@ -156,17 +161,24 @@ int launch_split_ns<2>(const ConvArgs& a, const SplitCfg& cfg, int KH, int KW, d
 template <>
 int launch_split_ns<3>(const ConvArgs& a, const SplitCfg& cfg, int KH, int KW, dim3 grid, dim3 block, hipStream_t stream);
 
-bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith) {
-    if ((arith != 3 && arith != 2) || stride != 1 || Cin % 16 != 0) return false;
+bool conv_split_supported(int KH, int KW, int Cin, int stride, int arith, int Cout) {
+    if ((arith != 3 && arith != 2) || (stride != 1 && stride != 2) || Cin % 16 != 0) return false;
+    // stride 2: planar sources only (checked at launch), and at least 3 output-channel blocks: the 9 x 17-position patch of a
+    // sub-tile is staged by the workgroup's output-channel waves, fewer of them would need more than 4 staging units per thread
+    if (stride == 2) return ((KH == 3 && KW == 3) || (KH == 1 && KW == 1)) && Cout >= 96;
     return (KH == 3 && KW == 3) || (KH == 1 && KW == 5) || (KH == 5 && KW == 1) || (KH == 1 && KW == 1);
 }
 
 int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, int epi, int B, int H, int W, hipStream_t stream) {
-    NND_REQUIRE(conv_split_supported(L.KH, L.KW, L.Cin, L.stride, L.arith), "conv_split: %dx%d Cin=%d stride %d arith %d not built",
-                L.KH, L.KW, L.Cin, L.stride, L.arith);
+    NND_REQUIRE(conv_split_supported(L.KH, L.KW, L.Cin, L.stride, L.arith, L.Cout), "conv_split: %dx%d Cin=%d Cout=%d stride %d arith %d not built",
+                L.KH, L.KW, L.Cin, L.Cout, L.stride, L.arith);
     NND_REQUIRE(io.src0.C + io.src1.C == L.Cin, "conv_split: source channels %d+%d != Cin %d", io.src0.C, io.src1.C, L.Cin);
     NND_REQUIRE(L.CI_T == 16 && L.nchunks * 16 == L.Cin, "conv_split: layer was not planned for 16-channel chunks");
-    NND_REQUIRE((long)(L.Cin + 64) * tiled_plane(H, W) < (1L << 31), "conv_split: plane offsets exceed 32 bits");
+    const int Hin = io.Hin > 0 ? io.Hin : H, Win = io.Win > 0 ? io.Win : W;  // input size (stride 2: the caller passes it)
+    NND_REQUIRE(L.stride == 1 ? (Hin == H && Win == W) : (H == (Hin + 1) / 2 && W == (Win + 1) / 2),
+                "conv_split: output %dx%d does not match input %dx%d at stride %d", H, W, Hin, Win, L.stride);
+    NND_REQUIRE(L.stride == 1 || (!io.src_c4 && io.src1.C == 0), "conv_split: stride 2 is built for one planar source");
+    NND_REQUIRE((long)(L.Cin + 64) * tiled_plane(Hin, Win) < (1L << 31), "conv_split: plane offsets exceed 32 bits");
     SplitCfg cfg;
     // FAST regime: any source layout the kernel addresses as plane + pixel offset — c4 tile-major (the refinement loops' own
     // tensors), planar tile-major (the encoder's) or NCHW (C-ABI tensors: cnet_proj reads the feature map, the Conv3d layers
@@ -186,13 +198,13 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     a.aux0 = io.aux0.ptr; a.abs0 = io.aux0.bstride;
     a.aux1 = io.aux1.ptr; a.abs1 = io.aux1.bstride;
     a.bmap = io.bmap.ptr; a.bmbs = io.bmap.bstride;
-    a.ls = make_lay(H, W, io.src_tiled, io.src_c4);
+    a.ls = make_lay(Hin, Win, io.src_tiled, io.src_c4);
     a.ld = make_lay(H, W, io.dst_tiled, io.dst_c4);
     NND_REQUIRE(!io.src_c4 || (io.src_tiled && io.src0.C % 4 == 0 && io.src1.C % 4 == 0), "conv_split: c4 sources need channel counts %% 4 == 0");
     NND_REQUIRE(!io.dst_c4 || (io.dst_tiled && (L.Cout % 4 == 0 || (!io.bmap.ptr && !io.aux0.ptr && !io.aux1.ptr && !io.out1.ptr))),
                 "conv_split: c4 destination with per-pixel operands needs Cout %% 4 == 0");
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
-    a.Hin = H; a.Win = W; a.flags = io.flags;
+    a.Hin = Hin; a.Win = Win; a.flags = io.flags;
     a.cscale = L.s_off >= 0 ? blob + L.s_off : nullptr;
     NND_REQUIRE(epi != EPI_AFFINE || a.cscale, "conv_split: EPI_AFFINE needs a packed scale vector");
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks; a.npos = cfg.ntiles;

@@ -16,6 +16,11 @@
 //           time: the walk was cut into ~20 basic blocks, each entered with conservative waits; round 3, profiles/r03_*)
 //   AD      steps (taps) of lookahead of the weight-fragment ring
 //   MAXT    launch bound (768: 3 waves per SIMD / 168 VGPRs; 512: 2 waves per SIMD / 256 VGPRs for the P >= 3 shapes)
+//   STR     stride 1 or 2 (2: 3x3 and 1x1, FAST regime with planar sources only — the encoder's and the regulariser's down-sampling
+//           layers).  The LDS patch of a stride-2 sub-tile is stored as its 4 (row, column) parity phases, each a dense grid with the
+//           stride-1 row / position strides: the operand of tap (dy, dx) for output pixel (r, c) — input (2r + dy, 2c + dx) — is
+//           then position (r + dy/2, c + dx/2) of phase (dy%2, dx%2): lane base + immediate with unit lane stride, conflict-free
+//           like the stride-1 patch.  A 1x1 stride-2 conv touches phase (0, 0) only and stages just those 4x8 positions.
 #pragma once
 #include "common.h"
 #include "conv_epilogue.h"
@@ -81,11 +86,24 @@ __device__ __forceinline__ void split_static_for(F&& f) {
     split_static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD_, int MAXT>
+// LDS geometry of one sub-tile's patch (bytes): stride 1: PR x PC positions; stride 2: 4 phases (1 for a 1x1) of PRP x PCP
+template <int KH, int KW, int NS, int STR>
+struct SplitGeom {
+    static constexpr int PRI = 3 * STR + KH, PCI = 7 * STR + KW;                 // input positions covered by a 4x8 output sub-tile
+    static constexpr int NPH = STR == 1 ? 1 : (KH * KW == 1 ? 1 : 4);            // parity phases stored
+    static constexpr int PRP = STR == 1 ? PRI : (KH == 1 ? 4 : (PRI + 1) / 2);   // rows / columns of a phase grid
+    static constexpr int PCP = STR == 1 ? PCI : (KW == 1 ? 8 : (PCI + 1) / 2);
+    static constexpr int NPOS = STR == 1 ? PRI * PCI : (KH * KW == 1 ? 32 : PRI * PCI);  // positions staged per sub-tile
+    static constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PCP, NS), PHB = PRP * ROWB, SUBB = NPH * PHB;
+};
+
+template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD_, int MAXT, int STR = 1>
 __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
+    static_assert(STR == 1 || (FAST && !SRC4 && (KH * KW == 9 || KH * KW == 1)), "stride 2: 3x3 / 1x1, FAST regime, planar sources");
+    using Geo = SplitGeom<KH, KW, NS, STR>;
     constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
-    constexpr int PR = 4 + KH - 1, PC = 8 + KW - 1, NPOS = PR * PC;
-    constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PC, NS), SUBB = PR * ROWB;
+    constexpr int PC = Geo::PCI, NPOS = Geo::NPOS;
+    constexpr int PS = Geo::PS, ROWB = Geo::ROWB, SUBB = Geo::SUBB, PHB = Geo::PHB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     NND_SSTAMP(0);
 
@@ -124,17 +142,30 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
         own[i] = u < nunits;
         const int pos = u % NPOS, rest = u / NPOS;
         const int pp = rest % P, oct = rest / P;
-        const int pr = pos / PC, pc = pos - pr * PC;
+        int pr, pc, lpos;  // input position relative to the sub-tile's first input row / column, and its byte offset in the patch
+        if constexpr (STR == 1) {
+            pr = pos / PC;
+            pc = pos - pr * PC;
+            lpos = pr * ROWB + pc * PS;
+        } else if constexpr (KH * KW == 1) {  // only the even (row, column) positions exist: phase (0, 0)
+            pr = (pos >> 3) * 2;
+            pc = (pos & 7) * 2;
+            lpos = (pos >> 3) * ROWB + (pos & 7) * PS;
+        } else {
+            pr = pos / PC;
+            pc = pos - pr * PC;
+            lpos = ((pr & 1) * 2 + (pc & 1)) * PHB + (pr >> 1) * ROWB + (pc >> 1) * PS;
+        }
         int gy = 0, gx = 0;
 #pragma unroll
         for (int q = 0; q < P; ++q)
             if (q == pp) {
-                gy = ty0[q] + pr - PH;
-                gx = tx0[q] + pc - PW;
+                gy = ty0[q] * STR + pr - PH;
+                gx = tx0[q] * STR + pc - PW;
             }
         inimg[i] = own[i] && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
         goff[i] = inimg[i] ? (int)pix_off(a.ls, gy, gx) : 0;
-        loff[i] = (oct >> 1) * (P * SUBB) + pp * SUBB + pr * ROWB + pc * PS + (oct & 1) * 16;
+        loff[i] = (oct >> 1) * (P * SUBB) + pp * SUBB + lpos + (oct & 1) * 16;
         cho[i] = oct * 8;
         if constexpr (FAST) goff[i] = inimg[i] ? cho[i] * (int)SP + goff[i] : 0;  // whole offset inside the super-chunk
     }
@@ -263,9 +294,10 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
         auto read_b = [&](int u, uint4 (&dst)[NS]) {
             const int t = u / P, pp = u % P;
             const int dy = t / KW, dx = t % KW;
+            const int toff = STR == 1 ? dy * ROWB + dx * PS : ((dy & 1) * 2 + (dx & 1)) * PHB + (dy >> 1) * ROWB + (dx >> 1) * PS;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + dy * ROWB + dx * PS + s * 32);
+                dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + toff + s * 32);
         };
 #pragma unroll
         for (int u = 0; u < NSLOT - 1 && u < NUNIT; ++u) read_b(u, bq[u]);
@@ -426,13 +458,14 @@ struct SplitCfg {
     int ny, wco, ks, P, ntiles, tiles_x, nu;
     bool fast;
     size_t lds;
+    int stride;
 };
 
 constexpr int SPLIT_MAX_WAVES = 12;
 
-template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD, int MAXT>
+template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD, int MAXT, int STR = 1>
 int launch_split_kernel(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
-    auto kern = conv_split_kernel<KH, KW, NS, P, NU, FAST, SRC4, AD, MAXT>;
+    auto kern = conv_split_kernel<KH, KW, NS, P, NU, FAST, SRC4, AD, MAXT, STR>;
     if ((int)block.x > MAXT) {
         set_error("conv_split: %u threads exceed the %d-thread bound of this instantiation", block.x, MAXT);
         return NND_ERR_INVALID;
@@ -464,6 +497,15 @@ template <int KH, int KW, int NS>
 int launch_split_shape(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
     constexpr int FAD = split_fast_ad<KH, KW, NS>();
     if (cfg.P != 2) return NND_ERR_UNSUPPORTED;
+    if (cfg.stride == 2) {  // FAST, planar sources (checked by the host)
+        if constexpr (KH * KW == 9 || KH * KW == 1) {
+            if (!cfg.fast || a.ls.ci == 4) return NND_ERR_UNSUPPORTED;
+            if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, false, FAD, 768, 2>(a, grid, block, cfg.lds, stream);
+            return launch_split_kernel<KH, KW, NS, 2, 4, true, false, FAD, 768, 2>(a, grid, block, cfg.lds, stream);
+        } else {
+            return NND_ERR_UNSUPPORTED;
+        }
+    }
     if (!cfg.fast) {
         if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, false, false, 1, 768>(a, grid, block, cfg.lds, stream);
         return launch_split_kernel<KH, KW, NS, 2, 4, false, false, 1, 768>(a, grid, block, cfg.lds, stream);

@@ -44,8 +44,9 @@ static int conv_layer(const nnd_conv_desc* d, ConvLayer* L, int64_t* total, int 
                     "conv: kernel %dx%d not built (1x1, 3x3, 1x5, 5x1)", d->KH, d->KW);
     ConvLayer l;
     l.KH = d->KH; l.KW = d->KW; l.Cin = d->Cin; l.Cout = d->Cout; l.stride = d->stride;
-    // the 1x1 projections stay on the streaming fp32 kernel (HBM-bound); 3x3 stride-1 layers may take the split kernel
-    if (arith != 0 && (k11 || !conv_split_supported(d->KH, d->KW, d->Cin, d->stride, arith))) arith = 0;
+    // the stride-1 1x1 projections stay on the streaming fp32 kernel (HBM-bound); 3x3 layers (stride 1 and 2) and the stride-2
+    // 1x1 shortcuts may take the split kernel
+    if (arith != 0 && ((k11 && d->stride == 1) || !conv_split_supported(d->KH, d->KW, d->Cin, d->stride, arith, d->Cout))) arith = 0;
     l.arith = arith;
     l.CI_T = arith ? 16 : conv_ci_t(d->KH, d->KW, d->Cin, d->stride, d->Cout);
     l.nchunks = cdiv(d->Cin, l.CI_T);
@@ -299,7 +300,7 @@ static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
         p->base1[i] = off; off += t;
         if ((rc = conv_layer(&b, &p->c2[i], &t, d->arithmetic)) != NND_OK) return rc;
         p->base2[i] = off; off += t;
-        if ((rc = conv_layer(&c, &p->ds[i], &t)) != NND_OK) return rc;
+        if ((rc = conv_layer(&c, &p->ds[i], &t, st == 2 ? d->arithmetic : 0)) != NND_OK) return rc;
         p->based[i] = off; off += t;
         cin = dim;
     }
