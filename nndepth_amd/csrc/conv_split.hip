@@ -121,7 +121,9 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
                     if (waves > SPLIT_MAX_WAVES || ks > L.nchunks) continue;
                     if (c1 > 0 && c0 % (ks * 16) != 0) continue;
                     const bool fast = fast_ok && L.nchunks % ks == 0;
-                    if (P > 2) continue;  // P = 3 / 4 are not instantiated (see launch_split_shape)
+                    if (P > 2) continue;  // P = 3 / 4 are not instantiated (see launch_split_shape; also measured for the encoder's
+                                          // 2-wave workgroups: 64 -> 64 at 272x480x2 takes 178 us with P = 4 against 111 with P = 2,
+                                          // profiles/r03_split_encoder_shapes.txt)
                     if (STR == 2 && !fast) continue;  // the stride-2 kernels exist in the FAST regime only
                     const int nu = cdiv(P * npos * 2 * ks, 64 * waves);  // staging units per thread
                     if (nu > 4 || (P == 3 && nu > 3)) continue;

@@ -1,5 +1,5 @@
 """Workgroup-shape sweep of conv_split.hip at the encoder's 3x3 shapes (544x960, 2 frames; NCHW tensors through
-nnd_conv2d_forward_ex): forced (ny, ks) via NND_SPLIT_CFG next to the picker's choice and to the exact fp32 kernel.
+nnd_conv2d_forward_ex): forced (ny, ks, P) via NND_SPLIT_CFG next to the picker's choice and to the exact fp32 kernel.
     python scripts/sweep_split_encoder.py        (on the GPU box; one subprocess per configuration)"""
 import os
 import subprocess
@@ -34,11 +34,13 @@ print(" ".join(out), flush=True)
 
 if __name__ == "__main__":
     print("columns: 64->64 @272x480x2   96->96 @136x240x2   128->128 @68x120x2   (us per launch, 3x3 + ReLU)")
-    for ar, cfg in [("fp32", None), ("bf16x3", None), ("bf16x3", "1,1"), ("bf16x3", "1,2"), ("bf16x3", "1,4"), ("bf16x3", "2,1"),
-                    ("bf16x3", "2,2"), ("bf16x3", "2,4"), ("bf16x3", "3,1"), ("bf16x3", "3,2"), ("bf16x3", "3,4"), ("bf16x3", "4,1"),
-                    ("bf16x3", "4,2"), ("bf16x3", "4,4")]:
+    ar2 = sys.argv[1] if len(sys.argv) > 1 else "fp16x2"
+    cfgs = [("fp32", None), (ar2, None), (ar2, "generic")] + [(ar2, f"{ny},{ks},{p}") for p in (2, 4) for ny in (1, 2, 3, 4) for ks in (1, 2, 4)]
+    for ar, cfg in cfgs:
         env = dict(os.environ, AB_ARITH=ar)
-        if cfg:
+        if cfg == "generic":
+            env["NND_SPLIT_NO_FAST"] = "1"
+        elif cfg:
             env["NND_SPLIT_CFG"] = cfg
         r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.strip() and "amdgpu" not in l]
