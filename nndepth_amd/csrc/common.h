@@ -45,6 +45,7 @@ struct Switches {
     unsigned split_mask;              // NND_SPLIT_MASK: bit = ConvId of the update-block convs that may take the split kernel
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
+    bool no_merged_fb_lookup;         // NND_NO_MERGED_FB_LOOKUP: flow branch and lookup + convc1 as two launches
     int conv_p, conv_ks, conv_wco;    // NND_CONV_CFG=p,ks,wco / NND_CONV_P
     int agcl_pb;                      // NND_AGCL_PB
 };
@@ -175,6 +176,11 @@ int agcl_offset_cl_launch(const float* f1c, const float* f2c, const float* flow,
 int nchw_to_nhwc_launch(const float* in, float* out, int N, int C, int P, hipStream_t s);
 int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
                          float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
+// the flow branch and lookup + convc1 of one iteration as ONE launch of two kinds of workgroups (corr1d.hip: flow_branch_lookup_kernel)
+bool flow_branch_lookup_supported(int arith);
+int flow_branch_lookup_launch(const ConvLayer& f2, const float* blob, const float* w7t, const float* b7, const float* flow, int64_t fbs,
+                              int fc, const ConvIO& io, const float* pyr, const float* coords, const ConvLayer& Lc1, float* c1,
+                              int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
 bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius);
 int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, const ConvLayer& L, const float* blob, float* c1,
                                  int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);

@@ -17,6 +17,7 @@
 // mul/mul/add rounding sequence bit for bit.
 #include <algorithm>
 #include "common.h"
+#include "flow_branch.h"
 #include "layout.h"
 
 namespace nnd {
@@ -459,15 +460,34 @@ __device__ __forceinline__ void store_c1(float* __restrict__ out_b, const Lay& l
 // convc1 weights (conv_mfma fragment order, CI_T = 32).  Saves a launch and the (B,cor_planes,H,W) round trip — 75 MB
 // per iteration for IGEV's 576 planes.  The accumulation order is conv_mfma's with ks = 1.
 // IGEV = true: two pyramids, channel = lvl*(2*G*T) + v*(G*T) + g*T + k (igev_stereo/cost_volume.py:54-79).
+// (the workgroup's work as a device function of its (tile, batch) index: lookup_convc1_kernel launches it alone,
+//  flow_branch_lookup_kernel beside the flow-branch workgroups of the same iteration)
+struct LookupC1Args {
+    const float* pyr;
+    const float* geo;
+    const float* coords;
+    const float* wpk;
+    const float* bias;
+    float* out;
+    long obs;
+    LookupArgs a;
+    int G, tiles_x, cb_stride, out_c4;
+};
+
 template <bool IGEV>
-__global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restrict__ pyr, const float* __restrict__ geo,
-                                                            const float* __restrict__ coords, const float* __restrict__ wpk,
-                                                            const float* __restrict__ bias, float* __restrict__ out, long obs,
-                                                            LookupArgs a, int G, int tiles_x, int cb_stride, int out_c4) {
-    __shared__ float xs[2][32 * 32];  // [buffer][channel of the chunk][pixel of the tile]
+__device__ __forceinline__ void lookup_convc1_body(const LookupC1Args& q, float (*xs)[32 * 32], const int bx, const int b) {
+    const float* __restrict__ pyr = q.pyr;
+    const float* __restrict__ geo = q.geo;
+    const float* __restrict__ coords = q.coords;
+    const float* __restrict__ wpk = q.wpk;
+    const float* __restrict__ bias = q.bias;
+    float* __restrict__ out = q.out;
+    const long obs = q.obs;
+    const LookupArgs& a = q.a;
+    const int G = q.G, tiles_x = q.tiles_x, cb_stride = q.cb_stride, out_c4 = q.out_c4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
-    const int tx0 = (blockIdx.x % tiles_x) * 8, ty0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.z;
+    const int tx0 = (bx % tiles_x) * 8, ty0 = (bx / tiles_x) * 4;
     const int ntap = 2 * a.radius + 1;
     const int nch = a.num_levels * ntap * (IGEV ? 2 * G : 1), nchunks = (nch + 31) / 32;
     const long HW = (long)a.H * a.W;
@@ -557,10 +577,32 @@ __global__ void __launch_bounds__(512) lookup_convc1_kernel(const float* __restr
     store_c1(out + (long)b * obs, a.lay, y, x, cb, h2, acc, br, out_c4);
 }
 
+template <bool IGEV>
+__global__ void __launch_bounds__(512) lookup_convc1_kernel(LookupC1Args q) {
+    __shared__ float xs[2][32 * 32];  // [buffer][channel of the chunk][pixel of the tile]
+    lookup_convc1_body<IGEV>(q, xs, (int)blockIdx.x, (int)blockIdx.z);
+}
+
+// Round 3: the motion encoder's flow branch and lookup + convc1 of one iteration as ONE launch of two kinds of workgroups.  The
+// two are independent (both read only the state the previous iteration left; convc2 / conv need both) and each alone is a
+// latency chain on one workgroup per CU (12.4 and 7.6 us at 68x120); both are 512-thread programs of 120 / 97 VGPRs whose LDS
+// (69 KB with fp16x2 pieces + 8 KB, allocated per workgroup: 2 x 69 KB) fits a CU twice, so a flow-branch and a lookup workgroup
+// run side by side on every CU.  Workgroups [0, nfb) of a batch item are flow-branch tiles, [nfb, 2 nfb) lookup tiles.  Same code
+// paths as the two kernels: bit-identical (tests/test_gpu_split.py).  RAFT-Stereo pyramids, arithmetic 2 (with 3 bf16 pieces
+// the flow branch's patch makes 2 x 82 KB, more than a CU has: the two launches stay).
+template <int FC, int NS>
+__global__ void __launch_bounds__(512) flow_branch_lookup_kernel(FlowBranchArgs fa, LookupC1Args q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fbl_lds[];
+    const int nfb = fa.c.npos;
+    if ((int)blockIdx.x < nfb) flow_branch_body<FC, NS>(fa, fbl_lds, (int)blockIdx.x, (int)blockIdx.z);
+    else lookup_convc1_body<false>(q, reinterpret_cast<float(*)[32 * 32]>(fbl_lds), (int)blockIdx.x - nfb, (int)blockIdx.z);
+}
+
 // coords (tile-major) -> c1 = relu(convc1(lookup(coords))) (tile-major, 256 channels); wpk / bias: the packed convc1 layer.
 // geo == nullptr: RAFT-Stereo pyramid; otherwise the IGEV feature + geometry pyramids with G groups.
-int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
-                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4) {
+static int lookup_convc1_launch_impl(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
+                                    float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream,
+                                    bool c1_c4, const FlowBranchArgs* fb, int fb_fc, int fb_ns) {
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 &&
                     L.Cin == num_levels * (2 * radius + 1) * (geo ? 2 * G : 1),
                 "lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
@@ -575,12 +617,45 @@ int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float*
     NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
     const int tiles_x = cdiv(W, 8);
     dim3 grid(tiles_x * cdiv(H, 4), 1, B), block(512);
-    if (geo)
-        hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, G, tiles_x, cb_stride, c1_c4 ? 1 : 0);
-    else
-        hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, block, 0, stream, pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, 1, tiles_x, cb_stride, c1_c4 ? 1 : 0);
+    LookupC1Args q{pyr, geo, coords, wpk, bias, c1, (long)c1_bs, a, geo ? G : 1, tiles_x, cb_stride, c1_c4 ? 1 : 0};
+    if (fb) {  // the flow-branch workgroups of the same iteration in the same launch
+        NND_REQUIRE(!geo && flow_branch_lookup_supported(fb_ns), "lookup_convc1: the merged flow-branch launch is built for RAFT-Stereo pyramids and arithmetic 2");
+        NND_REQUIRE(fb->c.npos == (int)grid.x && fb->c.tiles_x == tiles_x, "lookup_convc1: flow-branch tiling differs");
+        grid.x *= 2;
+        const size_t lds = fb_fc == 1 ? fb_lds_bytes<1, 2>() : fb_lds_bytes<2, 2>();
+        if (fb_fc == 1) {
+            static std::atomic<unsigned> raised{0};
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(flow_branch_lookup_kernel<1, 2>), raised)) return rc;
+            hipLaunchKernelGGL((flow_branch_lookup_kernel<1, 2>), grid, block, lds, stream, *fb, q);
+        } else {
+            static std::atomic<unsigned> raised{0};
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(flow_branch_lookup_kernel<2, 2>), raised)) return rc;
+            hipLaunchKernelGGL((flow_branch_lookup_kernel<2, 2>), grid, block, lds, stream, *fb, q);
+        }
+        NND_LAUNCH_CHECK();
+        return NND_OK;
+    }
+    if (geo) hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, block, 0, stream, q);
+    else hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, block, 0, stream, q);
     NND_LAUNCH_CHECK();
     return NND_OK;
+}
+
+bool flow_branch_lookup_supported(int arith) { return arith == 2; }
+
+int lookup_convc1_launch(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
+                         float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4) {
+    return lookup_convc1_launch_impl(pyr, geo, G, coords, L, blob, c1, c1_bs, B, H, W, num_levels, radius, stream, c1_c4, nullptr, 0, 0);
+}
+
+int flow_branch_lookup_launch(const ConvLayer& f2, const float* blob, const float* w7t, const float* b7, const float* flow, int64_t fbs,
+                              int fc, const ConvIO& io, const float* pyr, const float* coords, const ConvLayer& Lc1, float* c1,
+                              int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4) {
+    FlowBranchArgs fa;
+    int rc = make_flow_branch_args(f2, blob, w7t, b7, flow, fbs, fc, io, B, H, W, &fa);
+    if (rc != NND_OK) return rc;
+    return lookup_convc1_launch_impl(pyr, nullptr, 1, coords, Lc1, blob, c1, c1_bs, B, H, W, num_levels, radius, stream, c1_c4, &fa, fc,
+                                     f2.arith);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -792,6 +792,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_lk = switches().no_fused_lookup;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     const bool fused_lk = !cre && !no_fuse_lk;
+    const bool merged_fbl = fused_lk && !igev && !switches().no_merged_fb_lookup && !switches().no_fused_flow_branch &&
+                            flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith);
     // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
     auto loop_conv = [&](int id) -> int {
         probe_mark(id, s);
@@ -800,6 +802,16 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         return rc_;
     };
     for (int it = 0; it < iters; ++it) {
+        // RAFT-Stereo, arithmetic 2: the flow branch and lookup + convc1 — independent of each other — as ONE launch of two
+        // kinds of workgroups that share every CU (corr1d.hip: flow_branch_lookup_kernel)
+        if (merged_fbl) {
+            probe_mark(C_F2, s);
+            const ConvIO fio = conv_io(p, w, C_F2, c, n, nullptr, nullptr);
+            NND_TRY(flow_branch_lookup_launch(p.L[C_F2], packed, packed + p.f1_wt, packed + p.f1_b, w.flow, (int64_t)fc * n, fc, fio, pyramid,
+                                              w.coords, p.L[C_C1], w.c1, 256 * n, B, H, W, num_levels, radius, s, ws_c4()));
+            NND_TRY(debug_sync("encoder.convf1+convf2 | lookup+convc1", s));
+            probe_mark(C_F2, s);
+        } else {
         probe_mark(C_F2, s);
         NND_TRY(run_flow_branch(p, packed, w, w.flow, c, B, H, W, s));
         probe_mark(C_F2, s);
@@ -812,6 +824,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         } else {
             NND_TRY(lookup(s, it));
             NND_TRY(run_conv(p, packed, w, C_C1, c, nullptr, nullptr, B, H, W, s));
+        }
         }
         NND_TRY(loop_conv(C_C2));
         NND_TRY(loop_conv(C_CV));

@@ -300,3 +300,36 @@ def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc, ari
     for i, (x, y) in enumerate(zip(a, b)):
         assert torch.isfinite(x).all()
         assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
+def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monkeypatch, raft_sd):
+    """Round 3 (fp16x2, RAFT-Stereo): the motion encoder's flow branch and lookup + convc1 of an iteration run as ONE launch of two
+    kinds of workgroups (corr1d.hip: flow_branch_lookup_kernel).  Same device code as the two kernels: against the two launches
+    (NND_NO_MERGED_FB_LOOKUP) every output of the loop must match bit for bit — ragged 13x22 map, batch 2, and the 96x160 forward."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.cost_volume import CorrBlock1D
+    from nndepth_amd.raft_stereo import BaseRAFTStereo
+
+    def run():
+        torch.manual_seed(51)
+        B, H, W = 2, 13, 22
+        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic="fp16x2")
+        weightgen.fill_module_(ub, "update_block.")
+        eng = ub.to(DEV).eval().sync_engine(DEV)
+        net, inp = torch.tanh(torch.randn(B, 128, H, W)).to(DEV), torch.relu(torch.randn(B, 64, H, W)).to(DEV)
+        f1, f2 = torch.randn(B, 256, H, W, device=DEV), torch.randn(B, 256, H, W, device=DEV)
+        outs = [o.clone() for o in eng.refine(CorrBlock1D(f1, f2, 4, 4)._pyr, 4, 4, net, inp, 8, 4)]
+        m = BaseRAFTStereo(iters=5, context_dim=64)
+        m.load_state_dict(raft_sd, strict=True)
+        fr1, fr2 = weightgen.synthetic_frames(0, 1, 96, 160)
+        outs += [o["up_disp"].clone() for o in m.to(DEV).eval()(fr1.to(DEV), fr2.to(DEV))]
+        return outs
+
+    a = run()
+    monkeypatch.setenv("NND_NO_MERGED_FB_LOOKUP", "1")
+    b = run()
+    assert len(a) == len(b) == 8
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.isfinite(x).all() and x.abs().max() > 0
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
