@@ -603,9 +603,9 @@ __global__ void __launch_bounds__(512) flow_branch_lookup_kernel(FlowBranchArgs 
 static int lookup_convc1_launch_impl(const float* pyr, const float* geo, int G, const float* coords, const ConvLayer& L, const float* blob,
                                     float* c1, int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream,
                                     bool c1_c4, const FlowBranchArgs* fb, int fb_fc, int fb_ns) {
-    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 &&
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 && L.arith == 0 &&
                     L.Cin == num_levels * (2 * radius + 1) * (geo ? 2 * G : 1),
-                "lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
+                "lookup_convc1: layer %dx%d %d->%d (arithmetic %d) does not match the lookup", L.KH, L.KW, L.Cin, L.Cout, L.arith);
     const float* wpk = blob + L.w_off;
     const float* bias = blob + L.b_off;
     const int cb_stride = L.nchunks * (L.CI_T / 8) * 64;
@@ -807,6 +807,145 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_kernel(const flo
     }
 }
 
+// The same with convc1 in a split arithmetic (round 3; NS = 2: fp16x2, NS = 3: bf16x3, split_arith.h): convc1 of IGEV is a
+// 576 -> 256 GEMM (9.6 GFLOP per iteration at 136x240 — the largest of the IGEV iteration, 61 us at the fp32-MFMA peak); on the
+// 16-bit MFMA with split operands it is a fifth of that and the kernel is left with its gathers.  The blended samples are
+// split while they are written to LDS, in the B-fragment order of v_mfma_f32_32x32x16_* ([16-channel chunk][piece][k half]
+// [pixel][8 channels]: one conflict-free ds_read_b128 per piece and sub-tile); the weights are the layer in pack_conv_split's
+// order ([cb][chunk][piece][lane]), two chunks ahead in registers.  K order: level by level, chunk by chunk, products with
+// i + j descending — conv_split's order for ks = 1.
+template <int NS>
+__global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_split_kernel(const float* __restrict__ il, const float* __restrict__ coords,
+                                                                            const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                                            float* __restrict__ out, long obs, ILayout IL, Lay lay,
+                                                                            int H, int W, int num_levels, int ntiles, int tiles_x,
+                                                                            int out_c4) {
+    constexpr int NCHL = IL_LC / 16;                     // 16-channel chunks per level (9)
+    constexpr int LVB = NCHL * NS * 2 * 64 * 16;         // bytes of one level's B image: [chunk][piece][k half][64 pixels][8 x 16 bit]
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsb[];  // [2][LVB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const long HW = (long)H * W;
+    float br[16];
+    load_c1_bias(bias, wave, h2, br);
+    float oscale = 1.f;
+    if constexpr (NS == 2) oscale = bias[256];  // behind the 8 x 32 bias values of the packed layer (split_arith.h)
+    const int vg = tid & 15;
+    long pixo[2];
+    float cval[2];
+    bool pin[2];
+    int pcol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px64 = (tid >> 4) + 32 * i, t = blockIdx.x * 2 + (px64 >> 5), px = px64 & 31;
+        const int py = (t / tiles_x) * 4 + (px >> 3), pxx = (t % tiles_x) * 8 + (px & 7);
+        pin[i] = t < ntiles && py < H && pxx < W;
+        const long pix = pin[i] ? (long)py * W + pxx : 0;
+        pixo[i] = (long)b * HW + pix;
+        cval[i] = pin[i] ? coords[(long)b * lay.plane + pix_off(lay, py, pxx)] : 0.f;
+        pcol[i] = px64;
+    }
+    float v0[2][IL_NTAP], v1[2][IL_NTAP];
+    auto fetch = [&](int lvl) {
+        const int w2 = IL.width[lvl];
+        const float wm1 = (float)(w2 - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* base = il + IL.off[lvl] + pixo[i] * w2 * IL_VG + vg;
+#pragma unroll
+            for (int k = 0; k < IL_NTAP; ++k) {
+                float x = cval[i] / (float)(1 << lvl) + (float)(k - IL_NTAP / 2);
+                x = x / wm1;
+                x = fminf(fmaxf(x, 0.f), 1.f);
+                x = x * wm1;
+                v0[i][k] = base[(int)floorf(x) * IL_VG];
+                v1[i][k] = base[(int)ceilf(x) * IL_VG];
+            }
+        }
+    };
+    auto put = [&](int lvl, unsigned char* buf) {
+        const float wm1 = (float)(IL.width[lvl] - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < IL_NTAP; ++k) {
+                float x = cval[i] / (float)(1 << lvl) + (float)(k - IL_NTAP / 2);
+                x = x / wm1;
+                x = fminf(fmaxf(x, 0.f), 1.f);
+                x = x * wm1;
+                const float cf = ceilf(x) - x;
+                float res = pin[i] ? cf * v0[i][k] + (1.0f - cf) * v1[i][k] : 0.f;  // the sample, in the reference's op order
+                if constexpr (NS == 2) res = res * split_x_scale(2);
+                const int ch = vg * IL_NTAP + k;                              // channel inside the level
+                unsigned short* dst = reinterpret_cast<unsigned short*>(buf + (((ch >> 4) * NS * 2 + ((ch >> 3) & 1)) * 64 + pcol[i]) * 16) + (ch & 7);
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) {  // pieces: round-to-nearest of the running residual (split_arith.h)
+                    unsigned short bits;
+                    if constexpr (NS == 3) {
+                        const __bf16 pv = (__bf16)res;
+                        res -= (float)pv;
+                        bits = __builtin_bit_cast(unsigned short, pv);
+                    } else {
+                        const _Float16 pv = (_Float16)res;
+                        res -= (float)pv;
+                        bits = __builtin_bit_cast(unsigned short, pv);
+                    }
+                    dst[sp * (2 * 64 * 8)] = bits;  // next piece: 2 k halves x 64 pixels x 8 values further
+                }
+            }
+    };
+    fetch(0);
+    put(0, xsb);
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = 0.f, acc1[i] = 0.f;
+    // weights: uint4 index ((cb * nchunks + chunk) * NS + piece) * 64 + lane, a ring of 3 chunks
+    const int nchunks = num_levels * NCHL;
+    const uint4* wq = reinterpret_cast<const uint4*>(wpk) + (size_t)wave * nchunks * NS * 64 + lane;
+    auto load_a = [&](uint4 (&dst)[NS], int ch) {
+        const uint4* w = wq + (size_t)min(ch, nchunks - 1) * NS * 64;
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) dst[sp] = w[sp * 64];
+    };
+    uint4 ab[3][NS];
+    load_a(ab[0], 0);
+    load_a(ab[1], 1);
+    for (int lvl = 0; lvl < num_levels; ++lvl) {
+        const bool more = lvl + 1 < num_levels;
+        if (more) fetch(lvl + 1);
+        const unsigned char* xb = xsb + (lvl & 1) * LVB + (h2 * 64 + l31) * 16;
+#pragma unroll
+        for (int q = 0; q < NCHL; ++q) {  // NCHL = 9 = 3 x 3: the ring phase (lvl * NCHL + q) % 3 == q % 3 is a compile-time constant
+            load_a(ab[(q + 2) % 3], lvl * NCHL + q + 2);
+            uint4 b0[NS], b1[NS];
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                b0[sp] = *reinterpret_cast<const uint4*>(xb + ((q * NS + sp) * 2 * 64) * 16);
+                b1[sp] = *reinterpret_cast<const uint4*>(xb + ((q * NS + sp) * 2 * 64 + 32) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            split_mfma_step<NS>(ab[q % 3], b0, acc0);
+            split_mfma_step<NS>(ab[q % 3], b1, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) put(lvl + 1, xsb + ((lvl + 1) & 1) * LVB);
+        __syncthreads();
+    }
+    if constexpr (NS == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc0[i] *= oscale, acc1[i] *= oscale;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = blockIdx.x * 2 + p;
+        const int y = (t / tiles_x) * 4 + (l31 >> 3), x = (t % tiles_x) * 8 + (l31 & 7);
+        if (t >= ntiles || y >= H || x >= W) continue;
+        store_c1(out + (long)b * obs, lay, y, x, wave, h2, p ? acc1 : acc0, br, out_c4);
+    }
+}
+
 // false: shape not covered by the kernel above (the caller falls back to lookup_convc1_launch on the reference layout)
 bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius) {
     return 2 * G == IL_VG && 2 * radius + 1 == IL_NTAP && num_levels >= 1 && num_levels < MAX_LEVELS;
@@ -815,11 +954,29 @@ bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius) {
 int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, const ConvLayer& L, const float* blob, float* c1,
                                  int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4) {
     NND_REQUIRE(igev_lookup_convc1_il_supported(G, num_levels, radius), "igev_lookup_convc1: groups %d / radius %d not built", G, radius);
-    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.CI_T % 32 == 0 && L.Cin == num_levels * IL_LC,
+    NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.Cout == 256 && L.Cin == num_levels * IL_LC && (L.arith != 0 ? L.CI_T == 16 : L.CI_T % 32 == 0),
                 "igev_lookup_convc1: layer %dx%d %d->%d does not match the lookup", L.KH, L.KW, L.Cin, L.Cout);
     ILayout IL;
     make_il_layout(B, G, H, W, num_levels, &IL, nullptr);
     NND_REQUIRE(IL.width[num_levels - 1] >= 2, "igev_lookup_convc1: level %d has width %d < 2", num_levels - 1, IL.width[num_levels - 1]);
+    if (L.arith != 0) {  // convc1 packed for a split arithmetic
+        const int tiles_x = cdiv(W, 8), ntiles = tiles_x * cdiv(H, 4);
+        const size_t ldsb = (size_t)2 * (IL_LC / 16) * L.arith * 2 * 64 * 16;
+        dim3 grid(cdiv(ntiles, 2), 1, B), block(512);
+        if (L.arith == 2) {
+            static std::atomic<unsigned> raised2{0};
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(igev_lookup_convc1_il_split_kernel<2>), raised2)) return rc;
+            hipLaunchKernelGGL(igev_lookup_convc1_il_split_kernel<2>, grid, block, ldsb, stream, il, coords, blob + L.w_off, blob + L.b_off, c1,
+                               (long)c1_bs, IL, make_lay(H, W, true), H, W, num_levels, ntiles, tiles_x, c1_c4 ? 1 : 0);
+        } else {
+            static std::atomic<unsigned> raised3{0};
+            if (int rc = raise_lds_limit(reinterpret_cast<const void*>(igev_lookup_convc1_il_split_kernel<3>), raised3)) return rc;
+            hipLaunchKernelGGL(igev_lookup_convc1_il_split_kernel<3>, grid, block, ldsb, stream, il, coords, blob + L.w_off, blob + L.b_off, c1,
+                               (long)c1_bs, IL, make_lay(H, W, true), H, W, num_levels, ntiles, tiles_x, c1_c4 ? 1 : 0);
+        }
+        NND_LAUNCH_CHECK();
+        return NND_OK;
+    }
     const size_t lds = 2 * IL_LC * IL_S * sizeof(float);
     static std::atomic<unsigned> raised{0};
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(igev_lookup_convc1_il_kernel), raised)) return rc;

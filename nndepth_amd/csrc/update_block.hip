@@ -78,7 +78,10 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     p->sep = d->gru_kind == 0;
     int64_t off = 0;
     const int gin = hid + ctx + hid;
-    p->L[C_C1] = mk(1, 1, cp, 256, &off);
+    // convc1: split only where its K is whole 16-channel chunks (IGEV's 576 correlation planes: a 9.6-GFLOP GEMM per iteration at
+    // 136x240, fused with the interleaved lookup in igev_lookup_convc1_il_split_kernel); RAFT-Stereo's and CREStereo's 36 planes
+    // stay fp32 inside the fused lookup kernels (mk() falls back: 36 % 16 != 0)
+    p->L[C_C1] = mk(1, 1, cp, 256, &off, ar(C_C1));
     p->L[C_C2] = mk(3, 3, 256, 192, &off, ar(C_C2));
     p->f1_w = off; off += (int64_t)128 * fc * 49;
     p->f1_b = off; off += 128;
@@ -818,7 +821,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         if (fused_lk && interleaved && igev_lookup_convc1_il_supported(groups, num_levels, radius)) {  // IGEV over the group-interleaved copy of both pyramids
             NND_TRY(igev_lookup_convc1_il_launch(interleaved, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W, num_levels,
                                                  radius, s, ws_c4()));
-        } else if (fused_lk) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
+        } else if (fused_lk && p.L[C_C1].arith == 0) {  // lookup + convc1 in one kernel, the sampled features never reach HBM
             NND_TRY(lookup_convc1_launch(pyramid, geo_pyramid, groups, w.coords, p.L[C_C1], packed, w.c1, 256 * n, B, H, W,
                                          num_levels, radius, s, ws_c4()));
         } else {

@@ -127,7 +127,12 @@ def test_igev_config3_136x240_vs_oracle(R, B):
               "up_disp per iteration:", " ".join(f"{e:.2e}" for e in errs), f"(|up| max {exp[-1].abs().max().item():.0f}, ulp {ulp_up:.1e})")
         assert max(e_low.values()) <= 1e-4
         assert max(errs) <= 8 * ulp_up
-        assert torch.equal(up_il, up) and torch.equal(low_il, low)  # interleaved gather == reference-layout gather, bit for bit
+        # interleaved gather == reference-layout gather: bit for bit in fp32 (same kernel arithmetic); with a split convc1 the
+        # interleaved path runs its own K order (level by level inside the lookup kernel, conv_split's picker outside): rounding only
+        if ar == "fp32":
+            assert torch.equal(up_il, up) and torch.equal(low_il, low)
+        else:
+            assert (low_il - low).abs().max().item() <= 2e-5 and (up_il - up).abs().max().item() <= 4 * ulp_up
 
 
 def test_igev_config3_batch8_full_size_properties(R):
@@ -136,7 +141,7 @@ def test_igev_config3_batch8_full_size_properties(R):
     kernels), fused squeezer + soft-argmin, 8 iterations of the loop — in one call.  No CPU oracle finishes this in test
     time, so the size-independent properties carry it: (i) every sample of the batch equals the same sample run alone
     (k = 0, 5, 7; the batch index enters addresses only), (ii) pooled levels == avg_pool1d of the level below, bit-exact,
-    (iii) the loop over the interleaved copy == the loop over the reference-layout pyramids, bit for bit.  The single-sample
+    (iii) the loop over the interleaved copy == the loop over the reference-layout pyramids (bit for bit in fp32).  The single-sample
     path itself is pinned to the oracle by test_igev_config3_136x240_vs_oracle."""
     from nndepth_amd import ops, weightgen
     from nndepth_amd.blocks import BasicUpdateBlock
@@ -173,7 +178,10 @@ def test_igev_config3_batch8_full_size_properties(R):
         eng = ub.to(DEV).sync_engine(DEV)
         up8, low8, net8 = eng.refine_igev(cv8._feat, cv8._geo, G, 4, 4, d[2], d[3], 4, iters, disp_init=loop8, interleaved=il8)
         up8r, low8r, _ = eng.refine_igev(cv8._feat, cv8._geo, G, 4, 4, d[2], d[3], 4, iters, disp_init=loop8)
-        assert torch.equal(up8, up8r) and torch.equal(low8, low8r)  # (iii)
+        if ar == "fp32":
+            assert torch.equal(up8, up8r) and torch.equal(low8, low8r)  # (iii)
+        else:  # split convc1: the two paths sum K in different orders
+            assert (low8 - low8r).abs().max().item() <= 2e-5 and (up8 - up8r).abs().max().item() <= 5e-4
         del up8r, low8r
         inside = ((low8 >= 0) & (low8 <= W - 1)).float().mean().item()
         print(f"\n[config3 batch 8 {ar}] coordinates after {iters} iterations {low8.min().item():.1f} .. {low8.max().item():.1f}, {100 * inside:.1f} % on the map")
