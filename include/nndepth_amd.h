@@ -27,7 +27,9 @@
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_AGCL_V1 (one-pixel-per-lane AGCL kernels), NND_AGCL_PB (pixels per workgroup of the channels-last offset kernel), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
  *     (synchronise and name every launch of the update block on stderr), NND_NO_THIN3D (the regulariser's 8- / 16-channel
- *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip), NND_NO_C4 (planar instead of 4-channel-
+ *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip), NND_NO_SLAB3D (the same layers at stride 1 with
+ *     arithmetic = 2 through the round-2 formulations instead of the depth-marching MFMA kernel csrc/slab3d.hip),
+ *     NND_SLAB3D_ROUNDS (depth segments of that kernel: grid of about this many resident sets), NND_NO_C4 (planar instead of 4-channel-
  *     interleaved layout of the update block's conv-only workspace tensors).
  */
 #ifndef NNDEPTH_AMD_H
@@ -305,7 +307,9 @@ int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed_dev, con
  *   y = LeakyReLU_slope( BatchNorm3d_eval( conv3d(cat(x0, x1); w, stride, padding 1) + bias ) )        (norm / bias optional)
  * Volumes are DEPTH-MAJOR, (N, D+2, C, H, W) with one zero slice before and after the D real ones
  * (nnd_volume_to_depth_major / nnd_depth_major_to_volume convert from / to the usual (N, C, D, H, W)); a Conv3d is then one
- * launch of the 2-D MFMA convolution per sample over 3*C consecutive planes (csrc/conv3d.hip).  Cin1 = 0: single input.
+ * launch of the 2-D MFMA convolution per sample over 3*C consecutive planes (csrc/conv3d.hip); the thin layers (8 / 16 output
+ * channels) run on a direct VALU kernel (csrc/thin3d.hip; exact arithmetic, stride 2) or, with arithmetic = 2 at stride 1, on the
+ * depth-marching 16-bit-MFMA kernel (csrc/slab3d.hip).  Cin1 = 0: single input.
  * nnd_conv3d_pack (HOST): w (Cout, Cin0+Cin1, 3, 3, 3), bias / bn_* may be NULL.  leaky_slope 1 = no activation.          */
 typedef struct nnd_conv3d_desc {
     int Cout, Cin0, Cin1, stride;

@@ -198,15 +198,23 @@ int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
     const int J = group_of(desc);
     if (J > 1 && conv3d_layer(desc, J, &L, &tj) != NND_OK) return NND_ERR_INVALID;
     const int64_t tt = thin3d_supported(desc->Cout, desc->stride) ? thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
-    return t1 + tj + tt;  // [plain layer | J-slice grouped layer | thin-layer VALU kernel]
+    const int64_t ts = slab3d_supported(desc->Cout, desc->Cin0, desc->Cin1, desc->stride, desc->arithmetic)
+                           ? slab3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
+    return t1 + tj + tt + ts;  // [plain layer | J-slice grouped layer | thin-layer VALU kernel | depth-marching MFMA kernel]
 }
 
-// Which formulation a thin (Cout 8 / 16) layer takes.  Exact arithmetic: the direct VALU kernel of thin3d.hip on all of them
+// Which formulation a thin (Cout 8 / 16) layer takes.  fp16x2 at stride 1 (conv1.1, conv2_up, proj_2, conv1_up, final_conv):
+// use_slab above — the depth-marching MFMA kernel (round 3: 99 / 151 / 153 / 457 / 216 us against the numbers below).  Exact arithmetic: the direct VALU kernel of thin3d.hip on all of them
 // (NND_NO_THIN3D, diagnostic: the MFMA formulations above).  Split arithmetics: the J-slice grouped layer on the 16-bit MFMA
 // (conv_split, FAST regime on the depth-major slabs) wherever it is the faster one — measured per layer at 544x960 with fp16x2
 // (profiles/r03_igev_regulariser_layers_*.txt, us thin / MFMA): conv1.1 16->16 288 / 198, conv2_up 32->16 540 / 268, proj_2
 // 32->16 547 / 277, conv1_up 16->8 1020 / 876, but final_conv 8->8 533 / 600 (K = 6 x 8 x 9 is too short for the workgroup's
 // fixed phases) and the stride-2 layers 330 / 1041 (no stride-2 split kernel): those two kinds stay on the VALU kernel.
+// fp16x2, stride 1, the regulariser's (Cin, Cout) pairs: the depth-marching MFMA kernel of slab3d.hip (NND_NO_SLAB3D: the rules below)
+static bool use_slab(const nnd_conv3d_desc* d) {
+    return !switches().no_slab3d && slab3d_supported(d->Cout, d->Cin0, d->Cin1, d->stride, d->arithmetic);
+}
+
 static bool use_thin(const nnd_conv3d_desc* d) {
     if (switches().no_thin3d || !thin3d_supported(d->Cout, d->stride)) return false;
     if (d->arithmetic == 0 || d->stride != 1) return true;
@@ -279,6 +287,9 @@ int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bi
             sh[co] = (float)s0;
         }
         thin3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, w, sc.data(), sh.data(), packed_host + t1 + tj);
+        if (slab3d_supported(desc->Cout, desc->Cin0, desc->Cin1, desc->stride, desc->arithmetic))
+            slab3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, w, sc.data(), sh.data(),
+                        packed_host + t1 + tj + thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1));
     }
     return NND_OK;
 }
@@ -294,7 +305,7 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
     NND_REQUIRE(packed && x0 && y && (desc->Cin1 == 0 || x1), "conv3d_forward: null pointer");
     NND_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_forward: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    if (use_thin(desc)) {
+    if (use_slab(desc) || use_thin(desc)) {
         const int st0 = desc->stride;
         const int Do0 = (D + st0 - 1) / st0, Ho0 = (H + st0 - 1) / st0, Wo0 = (W + st0 - 1) / st0;
         const int64_t hwo0 = (int64_t)Ho0 * Wo0;
@@ -307,6 +318,9 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
         const int J0 = group_of(desc);
         ConvLayer LJ0;
         if (J0 > 1 && (rc = conv3d_layer(desc, J0, &LJ0, &tj0)) != NND_OK) return rc;
+        if (use_slab(desc))
+            return slab3d_forward(desc->Cout, desc->Cin0, desc->Cin1, packed + t1 + tj0 + thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1),
+                                  x0, x1, y, N, D, H, W, leaky_slope, s);
         return thin3d_forward(desc->Cout, desc->Cin0, desc->Cin1, st0, packed + t1 + tj0, x0, x1, y, N, D, H, W, leaky_slope, s);
     }
     int J = group_of(desc);

@@ -36,6 +36,8 @@ static void load_switches() {
     if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &s.conv_p, &s.conv_ks, &s.conv_wco);
     if (const char* e = getenv("NND_CONV_P")) s.conv_p = atoi(e);
     s.agcl_pb = getenv("NND_AGCL_PB") ? atoi(getenv("NND_AGCL_PB")) : 0;
+    s.no_slab3d = on("NND_NO_SLAB3D");
+    s.slab3d_rounds = getenv("NND_SLAB3D_ROUNDS") ? atoi(getenv("NND_SLAB3D_ROUNDS")) : 0;
     g_sw = s;
 }
 namespace {

@@ -234,6 +234,47 @@ def test_igev_regulariser_golden_split(gold, name, B, H, W, arith):
     assert err <= 2e-5
 
 
+@pytest.mark.parametrize("Cout,Cin,split,N,D,H,W,rounds", [
+    (8, 16, 0, 1, 12, 9, 14, 0), (8, 16, 0, 2, 7, 19, 45, 64), (8, 8, 0, 1, 5, 7, 13, 0), (8, 8, 0, 1, 20, 17, 36, 32),
+    (16, 32, 16, 1, 6, 8, 10, 0), (16, 32, 16, 2, 9, 11, 70, 48), (16, 32, 0, 1, 4, 5, 33, 0), (16, 16, 0, 1, 7, 10, 12, 0),
+    (16, 16, 0, 1, 13, 18, 40, 40)])
+def test_conv3d_depth_marching_mfma_vs_float64(monkeypatch, Cout, Cin, split, N, D, H, W, rounds):
+    """csrc/slab3d.hip: the regulariser's thin stride-1 Conv3d layers (conv1_up 16->8, final_conv 8->8, conv2_up / proj_2 32->16,
+    conv1.1 16->16) as the depth-marching fp16x2 MFMA kernel, against float64 Conv3d + BatchNorm3d(eval) + LeakyReLU: ragged
+    columns (H not a multiple of the 8- / 4-row column, W of 32 or 16), odd depths (Cout 8 walks two output slices per step),
+    batch 2, a channel concat, and several depth segments per column (NND_SLAB3D_ROUNDS raises the segment count on these small
+    volumes).  Same bar as the other formulations (3e-5); the fp32 VALU kernel's own error is printed beside it."""
+    from nndepth_amd import ops
+    if rounds:
+        monkeypatch.setenv("NND_SLAB3D_ROUNDS", str(rounds))
+    torch.manual_seed(Cout * 100 + Cin + D)
+    w = torch.randn(Cout, Cin, 3, 3, 3) * (2.0 / (Cin * 27)) ** 0.5
+    bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5)
+    x = torch.randn(N, Cin, D, H, W)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, stride=1, padding=1)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
+                                                                        False, 0.0, 1e-5), 0.01)
+    def run(ar):
+        conv = ops.Conv3dNorm(w, None, 1, bn, 1e-5, 0.01, split, DEV, arithmetic=ar)
+        if split:
+            y = conv(ops.volume_to_depth_major(x[:, :split].to(DEV)), ops.volume_to_depth_major(x[:, split:].to(DEV)))
+        else:
+            y = conv(ops.volume_to_depth_major(x.to(DEV)))
+        assert y[:, 0].abs().max() == 0 and y[:, -1].abs().max() == 0  # the zero end slices the next layer relies on
+        got = ops.depth_major_to_volume(y).cpu()
+        assert got.shape == ref.shape
+        return got
+
+    slab, exact = run("fp16x2"), run("fp32")
+    monkeypatch.setenv("NND_NO_SLAB3D", "1")  # the round-2 formulation of the same layer: the same fp16x2 products, another K order
+    other = run("fp16x2")
+    e_slab, e_exact, e_other = ((g.double() - ref).abs().max().item() for g in (slab, exact, other))
+    print(f"\nconv3d {Cin}->{Cout} {N}x{D}x{H}x{W}: max-abs vs float64: depth-marching MFMA {e_slab:.2e}, round-2 formulation {e_other:.2e}, "
+          f"exact fp32 VALU {e_exact:.2e}")
+    assert e_slab <= 3e-5 and e_slab <= 2.0 * e_exact + 2e-6
+    assert (slab - other).abs().max().item() <= 1e-5
+
+
 @pytest.mark.parametrize("fc", [1, 2])
 @pytest.mark.parametrize("arith", ARITHS)
 def test_fused_mask_upsample_split_matches_unfused(raft_sd, monkeypatch, fc, arith):
