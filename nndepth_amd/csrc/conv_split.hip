@@ -86,7 +86,9 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
     // (scripts/sweep_split_encoder.py): (ny,ks) = (1,1) 158 us | (1,2) 226 | (1,4) 326 | (2,1) 333; exact fp32 kernel 254.
     bool rule = false;
     if (L.nchunks <= 4 && !forced && L.ncb <= SPLIT_MAX_WAVES) {
+        // (at most 4 blocks per workgroup: IGEV's 64 -> 192 head conv as two groups of 3 — 136x240 41.6 -> 33.5 us, batch 8 304 -> 206)
         force_ny = 1;
+        while (force_ny < L.ncb && (L.ncb % force_ny != 0 || L.ncb / force_ny > 4)) ++force_ny;
         force_ks = 1;
         force_p = 2;
         rule = true;
@@ -96,13 +98,19 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
     // epilogue); with a long K (>= 16 chunks) at most 4 output-channel blocks per workgroup, with a short K all of them (the
     // patch staging then dominates and is done once).  Measured with scripts/sweep_split.py at 48x156 batch 8 against the
     // cost model below: zr 312 -> 280 us, q 202 -> 165, convc2 412 -> 379, conv 246 -> 228 (profiles/r02_split_wg_shape_sweep.txt).
-    if (!rule && px_wgs2 >= 448 && !forced && L.ncb <= SPLIT_MAX_WAVES) {
+    bool try_ks2 = false;
+    if (!rule && px_wgs2 >= 448 && !forced) {
         rule = true;
         force_ks = 1;
         force_ny = 1;
         force_p = 2;
-        if (L.nchunks >= 16)
-            while (force_ny < L.ncb && (L.ncb % force_ny != 0 || L.ncb / force_ny > 4)) ++force_ny;
+        const int max_wco = L.nchunks >= 16 ? 4 : SPLIT_MAX_WAVES;
+        while (force_ny < L.ncb && (L.ncb % force_ny != 0 || L.ncb / force_ny > max_wco)) ++force_ny;
+        // ... unless such workgroups leave most of the chip's wave slots empty (IGEV at 136x240, batch 1: 510 columns of 2-wave
+        // workgroups = 1020 waves for 3072 slots): then 2-way split K (4-wave workgroups).  Measured (scripts/sweep_split.py
+        // 136 240 1 fp16x2 igev, profiles/r03_split_shape_sweep_igev_136x240.txt): conv 256 -> 64 57.0 -> 42.7 us, q 28.4 -> 22.8;
+        // the same at batch 8 (4080 columns) and the 4-block zr conv (2040 waves) are not faster with it.
+        try_ks2 = px_wgs2 * force_ny * (L.ncb / force_ny) < 256 * SPLIT_MAX_WAVES / 2;
     }
     auto search = [&](int f_ny, int f_ks, int f_p) {
         double best = 1e30;
@@ -153,6 +161,7 @@ bool pick_split(const ConvLayer& L, int c0, int c1, int B, int H, int W, bool fa
         }
         return found;
     };
+    if (try_ks2 && search(force_ny, 2, force_p)) return true;
     if (search(force_ny, force_ks, force_p)) return true;
     return rule && search(-1, -1, -1);  // the regime rule's shape does not exist for this layer: the cost model decides
 }
