@@ -188,12 +188,23 @@ __global__ void __launch_bounds__(256) in_partial_kernel(const float* __restrict
     const int k = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
     const float* p = x + (long)n * bs + (long)c * lay.plane;
     double s = 0.0, q = 0.0;
-    const int HW = H * W;
-    for (int i = k * 256 + threadIdx.x; i < HW; i += IN_CHUNKS * 256) {
-        const int y = i / W, xx = i - y * W;
-        const double v = (double)p[pix_off(lay, y, xx)];
-        s += v;
-        q += v * v;
+    // the plane as it lies in memory (tile-major: 4x8-pixel tiles of 32 floats), 16 bytes per thread and step: group g = 4
+    // consecutive x of row (g % 8) / 2 of tile g / 8; the padding of the edge tiles holds no data and is skipped
+    // (first version: one pixel per thread through pix_off(y, x): 2.1 TB/s on the 540x960 maps of CREStereo's first stage)
+    const long ngroups = lay.plane / 4;
+    for (long g = (long)k * 256 + threadIdx.x; g < ngroups; g += IN_CHUNKS * 256) {
+        const long t = g >> 3;
+        const int y = (int)(t / lay.TX) * 4 + (int)((g & 7) >> 1), x0 = (int)(t % lay.TX) * 8 + (int)(g & 1) * 4;
+        if (y >= H || x0 >= W) continue;
+        const float4 v4 = *reinterpret_cast<const float4*>(p + g * 4);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < W) {
+                const double v = (double)vv[e];
+                s += v;
+                q += v * v;
+            }
     }
     sh[0][threadIdx.x] = s;
     sh[1][threadIdx.x] = q;
