@@ -45,9 +45,13 @@ struct Switches {
     unsigned split_mask;              // NND_SPLIT_MASK: bit = ConvId of the update-block convs that may take the split kernel
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
-    bool no_merged_fb_lookup;         // NND_NO_MERGED_FB_LOOKUP: flow branch and lookup + convc1 as two launches
+    bool merged_fb_lookup;            // NND_MERGED_FB_LOOKUP (opt-in): flow branch and lookup + convc1 as one launch of two kinds of workgroups
+    bool fb_shared_cu;                // NND_DEBUG_FB_SHARED_CU: the flow-branch launch asks for its exact LDS (other workgroups may share its CU)
     int conv_p, conv_ks, conv_wco;    // NND_CONV_CFG=p,ks,wco / NND_CONV_P
     int agcl_pb;                      // NND_AGCL_PB
+    bool lds_poison_on;               // NND_DEBUG_LDS_POISON=<pattern>: fill every CU's LDS with the pattern between the update block's launches
+    unsigned lds_poison;
+    int lds_slack;                    // NND_DEBUG_LDS_SLACK=<bytes>: conv_split launches ask for that much more dynamic LDS (diagnostic)
     bool no_slab3d;                   // NND_NO_SLAB3D: thin Conv3d layers on the round-2 formulations (conv_split / thin3d)
     int slab3d_rounds;                // NND_SLAB3D_ROUNDS: depth segments so that the grid is about this many resident sets
 };
@@ -150,12 +154,12 @@ void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, cons
 
 // thin3d.hip: direct fp32 VALU Conv3d for the regulariser's 8- / 16-output-channel layers (depth-major volumes)
 bool thin3d_supported(int Cout, int stride);
-// slab3d.hip: the same layers at stride 1 on the 16-bit MFMA (fp16x2), depth-marching with each input slice staged once
+// slab3d.hip: the regulariser's thin layers (stride 1 and 2) on the 16-bit MFMA (fp16x2), depth-marching with each input slice staged once
 bool slab3d_supported(int Cout, int C0, int C1, int stride, int arith);
-int64_t slab3d_packed_floats(int Cout, int Ct);
-void slab3d_pack(int Cout, int Ct, const float* w, const float* scale, const float* shift, float* out);
-int slab3d_forward(int Cout, int C0, int C1, const float* packed, const float* x0, const float* x1, float* y, int N, int D, int H, int W,
-                   float slope, hipStream_t s);
+int64_t slab3d_packed_floats(int Cout, int Ct, int stride);
+void slab3d_pack(int Cout, int Ct, int stride, const float* w, const float* scale, const float* shift, float* out);
+int slab3d_forward(int Cout, int C0, int C1, int stride, const float* packed, const float* x0, const float* x1, float* y, int N, int D,
+                   int H, int W, float slope, hipStream_t s);
 int64_t thin3d_packed_floats(int Cout, int Ct);
 void thin3d_pack(int Cout, int Ct, const float* w, const float* scale, const float* shift, float* out);
 int thin3d_forward(int Cout, int C0, int C1, int stride, const float* packed, const float* x0, const float* x1, float* y, int N, int D,

@@ -199,7 +199,7 @@ int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
     if (J > 1 && conv3d_layer(desc, J, &L, &tj) != NND_OK) return NND_ERR_INVALID;
     const int64_t tt = thin3d_supported(desc->Cout, desc->stride) ? thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
     const int64_t ts = slab3d_supported(desc->Cout, desc->Cin0, desc->Cin1, desc->stride, desc->arithmetic)
-                           ? slab3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
+                           ? slab3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1, desc->stride) : 0;
     return t1 + tj + tt + ts;  // [plain layer | J-slice grouped layer | thin-layer VALU kernel | depth-marching MFMA kernel]
 }
 
@@ -210,7 +210,7 @@ int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc) {
 // (profiles/r03_igev_regulariser_layers_*.txt, us thin / MFMA): conv1.1 16->16 288 / 198, conv2_up 32->16 540 / 268, proj_2
 // 32->16 547 / 277, conv1_up 16->8 1020 / 876, but final_conv 8->8 533 / 600 (K = 6 x 8 x 9 is too short for the workgroup's
 // fixed phases) and the stride-2 layers 330 / 1041 (no stride-2 split kernel): those two kinds stay on the VALU kernel.
-// fp16x2, stride 1, the regulariser's (Cin, Cout) pairs: the depth-marching MFMA kernel of slab3d.hip (NND_NO_SLAB3D: the rules below)
+// fp16x2, the regulariser's thin (Cin, Cout, stride) triples: the depth-marching MFMA kernel of slab3d.hip (NND_NO_SLAB3D: the rules below)
 static bool use_slab(const nnd_conv3d_desc* d) {
     return !switches().no_slab3d && slab3d_supported(d->Cout, d->Cin0, d->Cin1, d->stride, d->arithmetic);
 }
@@ -274,7 +274,9 @@ int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bi
         if ((rc = conv3d_layer(desc, J, &LJ, &tj)) != NND_OK) return rc;
         pack_one(desc, LJ, J, w, bias, bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, packed_host + t1);
     }
-    if (thin3d_supported(desc->Cout, desc->stride)) {  // same folded affine, weights in [ci][tap][co] order
+    const bool thin = thin3d_supported(desc->Cout, desc->stride);
+    const bool slab = slab3d_supported(desc->Cout, desc->Cin0, desc->Cin1, desc->stride, desc->arithmetic);
+    if (thin || slab) {  // same folded affine; weights in [ci][tap][co] order (VALU kernel) / as A fragments (depth-marching kernel)
         std::vector<float> sc(desc->Cout), sh(desc->Cout);
         for (int co = 0; co < desc->Cout; ++co) {
             const double b = bias ? (double)bias[co] : 0.0;
@@ -286,10 +288,9 @@ int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bi
             sc[co] = (float)s1;
             sh[co] = (float)s0;
         }
-        thin3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, w, sc.data(), sh.data(), packed_host + t1 + tj);
-        if (slab3d_supported(desc->Cout, desc->Cin0, desc->Cin1, desc->stride, desc->arithmetic))
-            slab3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, w, sc.data(), sh.data(),
-                        packed_host + t1 + tj + thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1));
+        const int64_t tt = thin ? thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
+        if (thin) thin3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, w, sc.data(), sh.data(), packed_host + t1 + tj);
+        if (slab) slab3d_pack(desc->Cout, desc->Cin0 + desc->Cin1, desc->stride, w, sc.data(), sh.data(), packed_host + t1 + tj + tt);
     }
     return NND_OK;
 }
@@ -318,9 +319,10 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
         const int J0 = group_of(desc);
         ConvLayer LJ0;
         if (J0 > 1 && (rc = conv3d_layer(desc, J0, &LJ0, &tj0)) != NND_OK) return rc;
-        if (use_slab(desc))
-            return slab3d_forward(desc->Cout, desc->Cin0, desc->Cin1, packed + t1 + tj0 + thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1),
-                                  x0, x1, y, N, D, H, W, leaky_slope, s);
+        if (use_slab(desc)) {
+            const int64_t tt0 = thin3d_supported(desc->Cout, st0) ? thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
+            return slab3d_forward(desc->Cout, desc->Cin0, desc->Cin1, st0, packed + t1 + tj0 + tt0, x0, x1, y, N, D, H, W, leaky_slope, s);
+        }
         return thin3d_forward(desc->Cout, desc->Cin0, desc->Cin1, st0, packed + t1 + tj0, x0, x1, y, N, D, H, W, leaky_slope, s);
     }
     int J = group_of(desc);

@@ -470,6 +470,7 @@ int launch_split_kernel(const ConvArgs& a, dim3 grid, dim3 block, size_t lds, hi
         set_error("conv_split: %u threads exceed the %d-thread bound of this instantiation", block.x, MAXT);
         return NND_ERR_INVALID;
     }
+    lds += switches().lds_slack;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned> raised{0};
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;

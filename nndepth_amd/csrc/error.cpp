@@ -31,11 +31,15 @@ static void load_switches() {
     s.split_ny = s.split_ks = s.split_p = -1;
     if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d,%d", &s.split_ny, &s.split_ks, &s.split_p);
     s.split_no_fast = on("NND_SPLIT_NO_FAST");
-    s.no_merged_fb_lookup = on("NND_NO_MERGED_FB_LOOKUP");
+    s.merged_fb_lookup = on("NND_MERGED_FB_LOOKUP");
+    s.fb_shared_cu = on("NND_DEBUG_FB_SHARED_CU");
     s.conv_p = s.conv_ks = s.conv_wco = -1;
     if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &s.conv_p, &s.conv_ks, &s.conv_wco);
     if (const char* e = getenv("NND_CONV_P")) s.conv_p = atoi(e);
     s.agcl_pb = getenv("NND_AGCL_PB") ? atoi(getenv("NND_AGCL_PB")) : 0;
+    s.lds_poison_on = on("NND_DEBUG_LDS_POISON");
+    s.lds_poison = s.lds_poison_on ? (unsigned)strtoul(getenv("NND_DEBUG_LDS_POISON"), nullptr, 0) : 0u;
+    s.lds_slack = getenv("NND_DEBUG_LDS_SLACK") ? atoi(getenv("NND_DEBUG_LDS_SLACK")) : 0;
     s.no_slab3d = on("NND_NO_SLAB3D");
     s.slab3d_rounds = getenv("NND_SLAB3D_ROUNDS") ? atoi(getenv("NND_SLAB3D_ROUNDS")) : 0;
     g_sw = s;

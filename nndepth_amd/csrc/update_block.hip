@@ -441,7 +441,22 @@ static int conv_epi(int id) {
 }
 
 // NND_DEBUG_SYNC=1: synchronise after every launch and name it on stderr (fault localisation only).
+// NND_DEBUG_LDS_POISON=<32-bit pattern> (diagnostic): after every launch of the update block a kernel that fills all of a CU's
+// LDS with the pattern runs on every CU, so a kernel that reads LDS it did not write itself computes with the pattern
+// instead of what the previous workgroup on that CU happened to leave (scripts/poison_lds.py)
+__global__ void __launch_bounds__(256) lds_poison_kernel(unsigned pattern) {
+    extern __shared__ unsigned poison_lds[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) poison_lds[i] = pattern;
+    __syncthreads();
+    if (poison_lds[(threadIdx.x * 97) % (160 * 1024 / 4)] != pattern) __builtin_trap();
+}
+
 static int debug_sync(const char* what, hipStream_t s) {
+    if (switches().lds_poison_on) {
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(lds_poison_kernel), raised)) return rc;
+        hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, s, switches().lds_poison);
+    }
     if (!switches().debug_sync) return NND_OK;
     fprintf(stderr, "[nnd] %s ...", what);
     fflush(stderr);
@@ -795,7 +810,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_lk = switches().no_fused_lookup;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     const bool fused_lk = !cre && !no_fuse_lk;
-    const bool merged_fbl = fused_lk && !igev && !switches().no_merged_fb_lookup && !switches().no_fused_flow_branch &&
+    // (opt-in since the flow branch must own its CU against OTHER streams' workgroups — conv_split.hip: launch_fb; in the merged launch
+    //  it shares the CU with the lookup workgroups by design, and next to a foreign stream's kernels it showed the same mismatches)
+    const bool merged_fbl = fused_lk && !igev && switches().merged_fb_lookup && !switches().no_fused_flow_branch &&
                             flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith);
     // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
     auto loop_conv = [&](int id) -> int {

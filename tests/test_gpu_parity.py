@@ -344,6 +344,49 @@ def test_two_host_threads_on_two_streams_equal_serial(raft_sd):
             assert torch.equal(results[i][k]["up_disp"], serial[i][k]), (i, k)
 
 
+def test_forward_is_reproducible_beside_another_streams_encoder(raft_sd):
+    """Regression for a round-3 finding: with the fused flow-branch kernel sharing its CU with ANOTHER stream's kernels (the small
+    workgroups of the fp16x2 encoder) 10-25 % of the forwards differed from the undisturbed result (a few sub-tiles of convf2's
+    output, ~1 % of the values).  The launch now owns its CU (csrc/conv_split.hip: launch_fb).  Victim: the RAFT-Stereo forward on
+    one stream, compared bit for bit with its undisturbed result; aggressor: a second host thread looping the fp16x2 encoder on
+    another stream.  120 forwards (the unfixed kernel failed 30-90 of 400 on every box tried)."""
+    import threading
+    from nndepth_amd import weightgen
+    victim, aggressor = _model(raft_sd, 6), _model(raft_sd, 2)
+    fr = tuple(f.to(DEV) for f in weightgen.synthetic_frames(20, 1, 96, 160))
+    afr = tuple(f.to(DEV) for f in weightgen.synthetic_frames(21, 1, 128, 160))
+    serial = [o["up_disp"].clone() for o in victim(*fr)]
+    aggressor(*afr)
+    torch.cuda.synchronize()
+    stop, errors = [False], []
+
+    def work():
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                while not stop[0]:
+                    aggressor.forward_fnet(*afr)
+                    st.synchronize()
+        except Exception as e:
+            errors.append(e)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    bad = 0
+    try:
+        st = torch.cuda.Stream(device=DEV)
+        with torch.cuda.stream(st):
+            for _ in range(120):
+                out = victim(*fr)
+                st.synchronize()
+                bad += any(not torch.equal(out[k]["up_disp"], serial[k]) for k in range(6))
+    finally:
+        stop[0] = True
+        th.join(timeout=60)
+    assert not errors, errors
+    assert bad == 0, f"{bad} of 120 forwards differ from the undisturbed result"
+
+
 def test_refine_wrappers_validate_shapes(raft_sd):
     """The refine entry points take raw pointers: the Python layer must reject a pyramid built at another resolution, a
     hidden state with the wrong channel count or a mis-shaped initial disparity (would be out-of-bounds device accesses)."""

@@ -234,13 +234,15 @@ def test_igev_regulariser_golden_split(gold, name, B, H, W, arith):
     assert err <= 2e-5
 
 
-@pytest.mark.parametrize("Cout,Cin,split,N,D,H,W,rounds", [
-    (8, 16, 0, 1, 12, 9, 14, 0), (8, 16, 0, 2, 7, 19, 45, 64), (8, 8, 0, 1, 5, 7, 13, 0), (8, 8, 0, 1, 20, 17, 36, 32),
-    (16, 32, 16, 1, 6, 8, 10, 0), (16, 32, 16, 2, 9, 11, 70, 48), (16, 32, 0, 1, 4, 5, 33, 0), (16, 16, 0, 1, 7, 10, 12, 0),
-    (16, 16, 0, 1, 13, 18, 40, 40)])
-def test_conv3d_depth_marching_mfma_vs_float64(monkeypatch, Cout, Cin, split, N, D, H, W, rounds):
-    """csrc/slab3d.hip: the regulariser's thin stride-1 Conv3d layers (conv1_up 16->8, final_conv 8->8, conv2_up / proj_2 32->16,
-    conv1.1 16->16) as the depth-marching fp16x2 MFMA kernel, against float64 Conv3d + BatchNorm3d(eval) + LeakyReLU: ragged
+@pytest.mark.parametrize("Cout,Cin,split,stride,N,D,H,W,rounds", [
+    (8, 16, 0, 1, 1, 12, 9, 14, 0), (8, 16, 0, 1, 2, 7, 19, 45, 64), (8, 8, 0, 1, 1, 5, 7, 13, 0), (8, 8, 0, 1, 1, 20, 17, 36, 32),
+    (16, 32, 16, 1, 1, 6, 8, 10, 0), (16, 32, 16, 1, 2, 9, 11, 70, 48), (16, 32, 0, 1, 1, 4, 5, 33, 0), (16, 16, 0, 1, 1, 7, 10, 12, 0),
+    (16, 16, 0, 1, 1, 13, 18, 40, 40),
+    (16, 8, 0, 2, 1, 12, 10, 16, 0), (16, 8, 0, 2, 2, 9, 19, 67, 48), (16, 8, 0, 2, 1, 7, 9, 130, 0),
+    (32, 16, 0, 2, 1, 7, 9, 11, 0), (32, 16, 0, 2, 2, 10, 18, 37, 32), (32, 16, 0, 2, 1, 5, 7, 66, 0)])
+def test_conv3d_depth_marching_mfma_vs_float64(monkeypatch, Cout, Cin, split, stride, N, D, H, W, rounds):
+    """csrc/slab3d.hip: the regulariser's thin Conv3d layers (stride 1: conv1_up 16->8, final_conv 8->8, conv2_up / proj_2 32->16,
+    conv1.1 16->16; stride 2: conv1.0 8->16, conv2.0 16->32, odd and even input sizes) as the depth-marching fp16x2 MFMA kernel, against float64 Conv3d + BatchNorm3d(eval) + LeakyReLU: ragged
     columns (H not a multiple of the 8- / 4-row column, W of 32 or 16), odd depths (Cout 8 walks two output slices per step),
     batch 2, a channel concat, and several depth segments per column (NND_SLAB3D_ROUNDS raises the segment count on these small
     volumes).  Same bar as the other formulations (3e-5); the fp32 VALU kernel's own error is printed beside it."""
@@ -251,11 +253,11 @@ def test_conv3d_depth_marching_mfma_vs_float64(monkeypatch, Cout, Cin, split, N,
     w = torch.randn(Cout, Cin, 3, 3, 3) * (2.0 / (Cin * 27)) ** 0.5
     bn = (torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5)
     x = torch.randn(N, Cin, D, H, W)
-    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, stride=1, padding=1)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, stride=stride, padding=1)
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(),
                                                                         False, 0.0, 1e-5), 0.01)
     def run(ar):
-        conv = ops.Conv3dNorm(w, None, 1, bn, 1e-5, 0.01, split, DEV, arithmetic=ar)
+        conv = ops.Conv3dNorm(w, None, stride, bn, 1e-5, 0.01, split, DEV, arithmetic=ar)
         if split:
             y = conv(ops.volume_to_depth_major(x[:, :split].to(DEV)), ops.volume_to_depth_major(x[:, split:].to(DEV)))
         else:
@@ -269,7 +271,7 @@ def test_conv3d_depth_marching_mfma_vs_float64(monkeypatch, Cout, Cin, split, N,
     monkeypatch.setenv("NND_NO_SLAB3D", "1")  # the round-2 formulation of the same layer: the same fp16x2 products, another K order
     other = run("fp16x2")
     e_slab, e_exact, e_other = ((g.double() - ref).abs().max().item() for g in (slab, exact, other))
-    print(f"\nconv3d {Cin}->{Cout} {N}x{D}x{H}x{W}: max-abs vs float64: depth-marching MFMA {e_slab:.2e}, round-2 formulation {e_other:.2e}, "
+    print(f"\nconv3d {Cin}->{Cout} stride {stride} {N}x{D}x{H}x{W}: max-abs vs float64: depth-marching MFMA {e_slab:.2e}, round-2 formulation {e_other:.2e}, "
           f"exact fp32 VALU {e_exact:.2e}")
     assert e_slab <= 3e-5 and e_slab <= 2.0 * e_exact + 2e-6
     assert (slab - other).abs().max().item() <= 1e-5
@@ -346,7 +348,7 @@ def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc, ari
 def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monkeypatch, raft_sd):
     """Round 3 (fp16x2, RAFT-Stereo): the motion encoder's flow branch and lookup + convc1 of an iteration run as ONE launch of two
     kinds of workgroups (corr1d.hip: flow_branch_lookup_kernel).  Same device code as the two kernels: against the two launches
-    (NND_NO_MERGED_FB_LOOKUP) every output of the loop must match bit for bit — ragged 13x22 map, batch 2, and the 96x160 forward."""
+    (the default; the merged launch is NND_MERGED_FB_LOOKUP=1) every output of the loop must match bit for bit — ragged 13x22 map, batch 2, and the 96x160 forward."""
     from nndepth_amd import weightgen
     from nndepth_amd.blocks import BasicUpdateBlock
     from nndepth_amd.cost_volume import CorrBlock1D
@@ -367,8 +369,9 @@ def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monke
         outs += [o["up_disp"].clone() for o in m.to(DEV).eval()(fr1.to(DEV), fr2.to(DEV))]
         return outs
 
+    monkeypatch.setenv("NND_MERGED_FB_LOOKUP", "1")  # opt-in: the default keeps the flow branch alone on its CU (csrc/conv_split.hip: launch_fb)
     a = run()
-    monkeypatch.setenv("NND_NO_MERGED_FB_LOOKUP", "1")
+    monkeypatch.delenv("NND_MERGED_FB_LOOKUP")
     b = run()
     assert len(a) == len(b) == 8
     for i, (x, y) in enumerate(zip(a, b)):
