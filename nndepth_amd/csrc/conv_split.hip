@@ -347,14 +347,6 @@ int make_flow_branch_args(const ConvLayer& f2, const float* blob, const float* w
     return NND_OK;
 }
 
-#ifdef NND_FB_DUMP
-extern "C" int nnd_debug_read_fb_dump(float* win_host, unsigned* patch_host) {
-    if (hipMemcpyFromSymbol(win_host, HIP_SYMBOL(g_fb_win), sizeof(float) * 64 * 256) != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(patch_host, HIP_SYMBOL(g_fb_patch), sizeof(unsigned) * 64 * 2048) != hipSuccess) return -1;
-    return 0;
-}
-#endif
-
 int launch_flow_branch(const ConvLayer& f2, const float* blob, const float* w7t, const float* b7, const float* flow, int64_t fbs,
                        int fc, const ConvIO& io, int B, int H, int W, hipStream_t stream) {
     FlowBranchArgs a;

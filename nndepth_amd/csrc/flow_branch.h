@@ -15,12 +15,6 @@ static __device__ unsigned long long g_fb_stamps[4096 * 8];
 #define NND_FSTAMP(i)
 #endif
 
-#ifdef NND_FB_DUMP
-// debug build: every workgroup leaves its flow window (as phase 1 saw it) and the first chunk of its f1 patch bytes in global memory
-static __device__ float g_fb_win[64][256];
-static __device__ unsigned g_fb_patch[64][2048];
-#endif
-
 struct FlowBranchArgs {
     const float* flow;  // (B, FC, H, W) planar tile-major
     long fbs;
@@ -31,22 +25,14 @@ struct FlowBranchArgs {
 };
 
 constexpr int FB_C1 = 128, FB_NCH = FB_C1 / 16, FB_PR = 6, FB_PC = 10, FB_WR = FB_PR + 6, FB_WC = FB_PC + 6;
-#ifdef NND_FB_ROWB800
-__host__ __device__ constexpr int fb_rowb(int NS) { return FB_PC * split_pos_bytes(NS); }
-#else
 __host__ __device__ constexpr int fb_rowb(int NS) { return split_row_bytes(FB_PC, NS); }
-#endif
 __host__ __device__ constexpr int fb_subb(int NS) { return FB_PR * fb_rowb(NS); }
 // LDS: [flow window | 7x7 weights | their bias] [convf2's patch]; the exchange buffer of phase 3 (3 slices x 2 blocks x 4 KB) aliases
 // the first region, which is dead once phase 1 has finished (a barrier separates them)
 template <int FC, int NS>
 __host__ __device__ constexpr int fb_lds_bytes() {
     constexpr int head = 4 * (FC * FB_WR * FB_WC + FC * 49 * FB_C1 + FB_C1), red = 2 * 3 * 1024 * 4;
-#ifdef NND_FB_NOALIAS
-    return head + red + FB_NCH * fb_subb(NS);
-#else
     return (head > red ? head : red) + FB_NCH * fb_subb(NS);
-#endif
 }
 
 // the workgroup's work as a device function of its (tile, batch) index: flow_branch_kernel launches it alone,
@@ -58,13 +44,8 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
     float* win = reinterpret_cast<float*>(lds_raw);                 // [FC][12][16]
     float* w7l = win + FC * FB_WR * FB_WC;                          // [FC*49][128]
     float* b7l = w7l + FC * 49 * FB_C1;                             // [128]
-#ifdef NND_FB_NOALIAS
-    unsigned char* patch = lds_raw + HEAD + RED;
-    float* red = reinterpret_cast<float*>(lds_raw + HEAD);
-#else
     unsigned char* patch = lds_raw + (HEAD > RED ? HEAD : RED);     // [8 chunks][6][ROWB]
     float* red = reinterpret_cast<float*>(lds_raw);                 // [3 slices][2 blocks][16 regs][64 lanes]: aliases win / w7l / b7l
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,11 +61,7 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
     float oscale = 1.f;
     if constexpr (NS == 2) oscale = a.c.bias[((a.c.Cout + 31) >> 5) << 5];  // undoes the fp16 range scaling (split_arith.h)
     constexpr int NSTEP = (FB_NCH / 4) * 9;  // (chunk, tap) steps of a K slice
-#ifdef NND_FB_AD
-    constexpr int FB_AD = NND_FB_AD, NA = FB_AD + 1;
-#else
     constexpr int FB_AD = 5, NA = FB_AD + 1;
-#endif
     uint4 ab[NA][NS];
     auto load_a = [&](uint4 (&dst)[NS], int st) {
         const int ch = 4 * (st / 9) + kj, t = st % 9;
@@ -97,11 +74,7 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase 0
-#ifdef NND_FB_WINALL
-    for (int e = lane; e < FC * FB_WR * FB_WC; e += 64) {  // every wave writes the whole window (same values)
-#else
     for (int e = tid; e < FC * FB_WR * FB_WC; e += 512) {
-#endif
         const int cch = e / (FB_WR * FB_WC), rr = (e / FB_WC) % FB_WR, cc = e % FB_WC;
         const int gy = ty0 + rr - 4, gx = tx0 + cc - 4;  // window row rr = patch row rr - 3 = image row ty0 - 1 + (rr - 3)
         win[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? a.flow[b * a.fbs + cch * FP + pix_off(a.lf, gy, gx)] : 0.f;
@@ -110,11 +83,6 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
         reinterpret_cast<float4*>(w7l)[e] = reinterpret_cast<const float4*>(a.w7t)[e];
     if (tid < FB_C1) b7l[tid] = a.b7[tid];
     __syncthreads();
-#ifdef NND_FB_SYNC1X2
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();
-#endif
     NND_FSTAMP(1);
 
     // ---- phase 1
@@ -166,18 +134,7 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
         }
     }
     __syncthreads();
-#ifdef NND_FB_SYNC1X2
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();
-#endif
     NND_FSTAMP(2);
-#ifdef NND_FB_DUMP
-    if (bx < 64) {
-        for (int e = tid; e < FC * FB_WR * FB_WC && e < 256; e += 512) g_fb_win[bx][e] = win[e];
-        for (int e = tid; e < 2048 && e * 4 < FB_NCH * SUBB; e += 512) g_fb_patch[bx][e] = reinterpret_cast<const unsigned*>(patch)[e];
-    }
-#endif
 
     // ---- phase 2
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -210,27 +167,12 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
 
     NND_FSTAMP(3);
     // ---- phase 3
-#ifdef NND_FB_SYNC3
-    __syncthreads();
-#endif
     if (kj > 0) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) red[(((kj - 1) * 2 + cbi) * 16 + reg) * 64 + lane] = acc[0][reg];
     }
     __syncthreads();
-#ifdef NND_FB_SYNC1X2
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();
-#endif
-#ifdef NND_FB_NOEARLYEXIT
-    if (kj > 0) {
-        __syncthreads();
-        return;
-    }
-#else
     if (kj > 0) return;
-#endif
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         float sum = acc[0][reg];
@@ -266,9 +208,6 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     NND_FSTAMP(4);
-#ifdef NND_FB_NOEARLYEXIT
-    __syncthreads();
-#endif
 }
 
 template <int FC, int NS>

@@ -30,7 +30,7 @@ base_cf = cf_snapshot()
 import ctypes as C, numpy as np
 from nndepth_amd._lib import LIB_PATH
 raw = C.CDLL(LIB_PATH)
-DUMP = hasattr(raw, "nnd_debug_read_fb_dump")
+DUMP = hasattr(raw, "nnd_debug_read_fb_dump")  # only in an experimental build that dumped the kernel's LDS (not kept)
 
 
 def fb_dump():
