@@ -518,7 +518,10 @@ static int run_flow_branch(const Plan& p, const float* blob, const Bufs& w, cons
                            hipStream_t s) {
     const int fc = p.d.flow_channels;
     const int64_t n = tiled_plane(H, W);
-    if (flow_branch_supported(p.L[C_F2], fc) && !switches().no_fused_flow_branch) {
+    // the fused kernel owns its CU (conv_split.hip: launch_fb): up to one workgroup (4x8 sub-tile) per CU that costs nothing; on
+    // larger grids the two launches are as fast or faster (KITTI batch 8 46.6 vs 47.0 ms, IGEV batch 8 115.0 vs 119.2 ms per batch)
+    const bool one_round = (long)cdiv(H, 4) * cdiv(W, 8) * B <= 256;
+    if (flow_branch_supported(p.L[C_F2], fc) && !switches().no_fused_flow_branch && one_round) {
         const ConvIO io = conv_io(p, w, C_F2, corr, n, nullptr, nullptr);
         int rc = launch_flow_branch(p.L[C_F2], blob, blob + p.f1_wt, blob + p.f1_b, flow, (int64_t)fc * n, fc, io, B, H, W, s);
         if (rc != NND_OK) return rc;
@@ -813,7 +816,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     // (opt-in since the flow branch must own its CU against OTHER streams' workgroups — conv_split.hip: launch_fb; in the merged launch
     //  it shares the CU with the lookup workgroups by design, and next to a foreign stream's kernels it showed the same mismatches)
     const bool merged_fbl = fused_lk && !igev && switches().merged_fb_lookup && !switches().no_fused_flow_branch &&
-                            flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith);
+                            flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith) &&
+                            (long)cdiv(H, 4) * cdiv(W, 8) * B <= 256;
     // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
     auto loop_conv = [&](int id) -> int {
         probe_mark(id, s);
