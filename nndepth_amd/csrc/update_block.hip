@@ -504,9 +504,17 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     if (fc == 1)
         hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
                            delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance, absolute ? 1 : 0, lay);
-    else
-        hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
+    else {
+        // the 2-channel variant asks for a whole CU's LDS: like the fused flow branch (conv_split.hip: launch_fb) it gave results
+        // that depended on foreign workgroups sharing its CU — one update-block step beside another stream's fp16x2 encoder: 48-55
+        // of 200 steps with a different `delta`, every other workspace tensor identical (scripts/race_ub_buffers.py); the
+        // 1-channel variant never did (0 of 600).  NND_DEBUG_FB_SHARED_CU restores the exact request.
+        static std::atomic<unsigned> raised{0};
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(flow_head2_kernel<2>), raised)) return rc;
+        const size_t lds2 = switches().fb_shared_cu ? lds : (size_t)160 * 1024;
+        hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds2, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
                            delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
+    }
     NND_LAUNCH_CHECK();
     return debug_sync("flow_head.conv2", s);
 }

@@ -387,6 +387,52 @@ def test_forward_is_reproducible_beside_another_streams_encoder(raft_sd):
     assert bad == 0, f"{bad} of 120 forwards differ from the undisturbed result"
 
 
+def test_cre_forward_is_reproducible_beside_another_streams_encoder(raft_sd, cre_sd):
+    """The same for the CREStereo cascade (fp16x2 and exact fp32): its 2-channel `flow_head.conv2` kernel showed the same
+    dependence on foreign workgroups sharing its CU (48-55 of 200 update-block steps with a different `delta`,
+    scripts/race_ub_buffers.py) and owns its CU as well (csrc/update_block.hip: run_fc2).  60 forwards per arithmetic."""
+    import threading
+    from nndepth_amd import weightgen
+    from nndepth_amd.cre_stereo import CREStereoBase
+    aggressor = _model(raft_sd, 2)
+    afr = tuple(f.to(DEV) for f in weightgen.synthetic_frames(21, 1, 128, 160))
+    aggressor(*afr)
+    fr = tuple(f.to(DEV) for f in weightgen.synthetic_frames(3, 1, 256, 320))
+    for ar in ("fp16x2", "fp32"):
+        victim = CREStereoBase(iters=2, arithmetic=ar)
+        victim.load_state_dict(cre_sd, strict=True)
+        victim = victim.to(DEV).eval()
+        serial = [o["up_disp"].clone() for o in victim(*fr)]
+        torch.cuda.synchronize()
+        stop, errors = [False], []
+
+        def work():
+            try:
+                st = torch.cuda.Stream(device=DEV)
+                with torch.cuda.stream(st):
+                    while not stop[0]:
+                        aggressor.forward_fnet(*afr)
+                        st.synchronize()
+            except Exception as e:
+                errors.append(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        bad = 0
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                for _ in range(60):
+                    out = victim(*fr)
+                    st.synchronize()
+                    bad += any(not torch.equal(o["up_disp"], s_) for o, s_ in zip(out, serial))
+        finally:
+            stop[0] = True
+            th.join(timeout=60)
+        assert not errors, errors
+        assert bad == 0, f"{ar}: {bad} of 60 forwards differ from the undisturbed result"
+
+
 def test_refine_wrappers_validate_shapes(raft_sd):
     """The refine entry points take raw pointers: the Python layer must reject a pyramid built at another resolution, a
     hidden state with the wrong channel count or a mis-shaped initial disparity (would be out-of-bounds device accesses)."""
