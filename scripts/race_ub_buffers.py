@@ -53,6 +53,13 @@ try:
                 d = ws != base_ws
                 which = tuple(nm for nm, of, sz in zip(names, offs, sizes) if bool(d[of:of + sz * n].any()))
                 hist[which] = hist.get(which, 0) + 1
+                if bad <= 6 and "delta" in which:
+                    of = offs[names.index("delta")]
+                    dd = (ws[of:of + fc * n] - base_ws[of:of + fc * n]).view(fc, n // 32, 32)
+                    nzt = sorted(set(dd.abs().sum(2).nonzero()[:, 1].tolist()))
+                    t0 = nzt[0]
+                    print(f"   rep {rep}: delta differs in sub-tiles {nzt[:12]} ({len(nzt)}); sub-tile {t0}: channel 0 diffs {[round(float(v), 5) for v in dd[0, t0]]}")
+                    print(f"            channel 1 diffs {[round(float(v), 5) for v in dd[1, t0]] if fc > 1 else None}; values ch0 {[round(float(v), 3) for v in base_ws[of:of + n].view(-1, 32)[t0][:8]]}")
 finally:
     stop[0] = True; th.join(timeout=60)
 print(f"[update block step {ar} fc={fc} ctx={ctx} {H}x{W}] {bad} of {reps} differ; workspace tensors differing: {hist}")
