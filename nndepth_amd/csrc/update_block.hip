@@ -511,7 +511,7 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
         // 1-channel variant never did (0 of 600).  NND_DEBUG_FB_SHARED_CU restores the exact request.
         static std::atomic<unsigned> raised{0};
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(flow_head2_kernel<2>), raised)) return rc;
-        const size_t lds2 = switches().fb_shared_cu ? lds : (size_t)160 * 1024;
+        const size_t lds2 = switches().fb_shared_cu ? lds + switches().lds_slack : (size_t)160 * 1024;
         hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds2, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
                            delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
     }
