@@ -21,7 +21,7 @@
  *   - diagnostic environment switches (read ONCE when the library is loaded and again only by nnd_reload_switches(), never
  *     on the hot path; they select between kernels that the parity tests prove equivalent, never a non-HIP path; the
  *     packed-blob layout depends on NND_SPLIT_MASK, so do not reload between a pack and the forwards that use the blob): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
- *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_MERGED_FB_LOOKUP (opt-in: flow branch and lookup + convc1 as one launch of two kinds of workgroups; +2 % at batch 1, but the flow branch then shares its CU — see NND_DEBUG_FB_SHARED_CU), NND_DEBUG_FB_SHARED_CU (the fused flow-branch launch and the 2-channel flow_head.conv2 launch ask for their exact LDS instead of a whole CU's: next to other streams' kernels its result was then not reproducible, csrc/conv_split.hip: launch_fb), NND_SPLIT_NO_FAST (the generic conv_split kernel everywhere), NND_NO_FUSED_FLOW_BRANCH (convf1 and convf2 as two launches when
+ *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_MERGED_FB_LOOKUP (flow branch and lookup + convc1 as two launches instead of one launch of two kinds of workgroups), NND_DEBUG_LDS_POISON / NND_DEBUG_LDS_SLACK (diagnostics of the round-3 reproducibility study: pattern-fill every CU's LDS between the loop's launches / ask for more dynamic LDS), NND_SPLIT_NO_FAST (the generic conv_split kernel everywhere), NND_NO_FUSED_FLOW_BRANCH (convf1 and convf2 as two launches when
  *     arithmetic = 3), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
  *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_AGCL_V1 (one-pixel-per-lane AGCL kernels), NND_AGCL_PB (pixels per workgroup of the channels-last offset kernel), NND_CONV_CFG / NND_CONV_P

@@ -45,8 +45,7 @@ struct Switches {
     unsigned split_mask;              // NND_SPLIT_MASK: bit = ConvId of the update-block convs that may take the split kernel
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
-    bool merged_fb_lookup;            // NND_MERGED_FB_LOOKUP (opt-in): flow branch and lookup + convc1 as one launch of two kinds of workgroups
-    bool fb_shared_cu;                // NND_DEBUG_FB_SHARED_CU: the flow-branch launch asks for its exact LDS (other workgroups may share its CU)
+    bool no_merged_fb_lookup;         // NND_NO_MERGED_FB_LOOKUP: flow branch and lookup + convc1 as two launches
     int conv_p, conv_ks, conv_wco;    // NND_CONV_CFG=p,ks,wco / NND_CONV_P
     int agcl_pb;                      // NND_AGCL_PB
     bool lds_poison_on;               // NND_DEBUG_LDS_POISON=<pattern>: fill every CU's LDS with the pattern between the update block's launches

@@ -306,19 +306,7 @@ static int launch_fb(const FlowBranchArgs& a, dim3 grid, dim3 block, hipStream_t
     auto kern = flow_branch_kernel<FC, NS>;
     static std::atomic<unsigned> raised{0};
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
-    // The launch asks for ALL of a CU's LDS, although the body uses fb_lds_bytes (69 KB with fp16x2): a flow-branch workgroup must
-    // not share its CU with workgroups of OTHER kernels.  Found with two host threads on two streams (tests/test_gpu_parity.py):
-    // beside another stream's fp16x2 encoder kernels (2-wave workgroups that fit next to this 8-wave, 120-VGPR, 69-KB one) 10-25 %
-    // of the steps came out different from the undisturbed result — a few sub-tiles, output rows 1..3 of the 4x8 tile, ~1 % of
-    // the values' size; never alone on the device, never for any other kernel of the loop (they fill their CU's registers), and
-    // in 0 of 1200 steps / 800 forwards once the workgroup owns its CU (scripts/race_step.py, race_aggressor.py;
-    // profiles/r03_flow_branch_coresidency.txt).  The window and the first patch chunks the workgroup leaves in LDS were correct
-    // in the failing steps; doubling every barrier, removing the LDS aliasing and the early exit of the K-slice waves, a one-deep
-    // weight ring, every wave writing the whole window or an LDS image below 64 KB did not remove it — the mechanism is not
-    // understood, the condition (co-residency with foreign workgroups) is, so it is excluded.  Cost: none at 68x120 (255
-    // workgroups, one per CU either way); larger grids run one instead of two per CU.  NND_DEBUG_FB_SHARED_CU (diagnostic)
-    // restores the exact request.
-    const size_t lds = switches().fb_shared_cu ? (size_t)(fb_lds_bytes<FC, NS>()) + switches().lds_slack : (size_t)160 * 1024;
+    const size_t lds = (size_t)(fb_lds_bytes<FC, NS>()) + switches().lds_slack;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     return NND_OK;
 }

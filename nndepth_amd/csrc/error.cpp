@@ -31,8 +31,7 @@ static void load_switches() {
     s.split_ny = s.split_ks = s.split_p = -1;
     if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d,%d", &s.split_ny, &s.split_ks, &s.split_p);
     s.split_no_fast = on("NND_SPLIT_NO_FAST");
-    s.merged_fb_lookup = on("NND_MERGED_FB_LOOKUP");
-    s.fb_shared_cu = on("NND_DEBUG_FB_SHARED_CU");
+    s.no_merged_fb_lookup = on("NND_NO_MERGED_FB_LOOKUP");
     s.conv_p = s.conv_ks = s.conv_wco = -1;
     if (const char* e = getenv("NND_CONV_CFG")) sscanf(e, "%d,%d,%d", &s.conv_p, &s.conv_ks, &s.conv_wco);
     if (const char* e = getenv("NND_CONV_P")) s.conv_p = atoi(e);

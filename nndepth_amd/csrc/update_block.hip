@@ -504,17 +504,9 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     if (fc == 1)
         hipLaunchKernelGGL(flow_head2_kernel<1>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
                            delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance, absolute ? 1 : 0, lay);
-    else {
-        // the 2-channel variant asks for a whole CU's LDS: like the fused flow branch (conv_split.hip: launch_fb) it gave results
-        // that depended on foreign workgroups sharing its CU — one update-block step beside another stream's fp16x2 encoder: 48-55
-        // of 200 steps with a different `delta`, every other workspace tensor identical (scripts/race_ub_buffers.py); the
-        // 1-channel variant never did (0 of 600).  NND_DEBUG_FB_SHARED_CU restores the exact request.
-        static std::atomic<unsigned> raised{0};
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(flow_head2_kernel<2>), raised)) return rc;
-        const size_t lds2 = switches().fb_shared_cu ? lds + switches().lds_slack : (size_t)160 * 1024;
-        hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds2, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
+    else
+        hipLaunchKernelGGL(flow_head2_kernel<2>, grid, block, lds, s, w.fm, (long)(3 * hid * n), hid, blob + p.fc2_w, blob + p.fc2_b,
                            delta_dst, w.coords, w.flow, hx_flow, (long)(hxC * n), hx_cs, ws_pm(), ws_c4() ? 1 : 0, H, W, tiles_x, advance == 2 ? 2 : 0, 0, lay);
-    }
     NND_LAUNCH_CHECK();
     return debug_sync("flow_head.conv2", s);
 }
@@ -526,10 +518,7 @@ static int run_flow_branch(const Plan& p, const float* blob, const Bufs& w, cons
                            hipStream_t s) {
     const int fc = p.d.flow_channels;
     const int64_t n = tiled_plane(H, W);
-    // the fused kernel owns its CU (conv_split.hip: launch_fb): up to one workgroup (4x8 sub-tile) per CU that costs nothing; on
-    // larger grids the two launches are as fast or faster (KITTI batch 8 46.6 vs 47.0 ms, IGEV batch 8 115.0 vs 119.2 ms per batch)
-    const bool one_round = (long)cdiv(H, 4) * cdiv(W, 8) * B <= 256;
-    if (flow_branch_supported(p.L[C_F2], fc) && !switches().no_fused_flow_branch && one_round) {
+    if (flow_branch_supported(p.L[C_F2], fc) && !switches().no_fused_flow_branch) {
         const ConvIO io = conv_io(p, w, C_F2, corr, n, nullptr, nullptr);
         int rc = launch_flow_branch(p.L[C_F2], blob, blob + p.f1_wt, blob + p.f1_b, flow, (int64_t)fc * n, fc, io, B, H, W, s);
         if (rc != NND_OK) return rc;
@@ -821,11 +810,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_lk = switches().no_fused_lookup;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     const bool fused_lk = !cre && !no_fuse_lk;
-    // (opt-in since the flow branch must own its CU against OTHER streams' workgroups — conv_split.hip: launch_fb; in the merged launch
-    //  it shares the CU with the lookup workgroups by design, and next to a foreign stream's kernels it showed the same mismatches)
-    const bool merged_fbl = fused_lk && !igev && switches().merged_fb_lookup && !switches().no_fused_flow_branch &&
-                            flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith) &&
-                            (long)cdiv(H, 4) * cdiv(W, 8) * B <= 256;
+    const bool merged_fbl = fused_lk && !igev && !switches().no_merged_fb_lookup && !switches().no_fused_flow_branch &&
+                            flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith);
     // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
     auto loop_conv = [&](int id) -> int {
         probe_mark(id, s);

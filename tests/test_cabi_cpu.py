@@ -266,3 +266,33 @@ def test_patch_swaps_the_seams_of_the_imported_reference_model(raft_sd):
         for k in set(sys.modules) - set(saved[0]):
             del sys.modules[k]
         sys.path[:] = saved[1]
+
+
+def test_no_packed_fp32_fma_in_the_update_blocks_valu_convolutions(tmp_path):
+    """Round-3 finding (profiles/r03_flow_branch_coresidency.txt): the packed-fp32 FMAs the SLP vectoriser formed in
+    the fused flow-branch kernel and in the 2-channel flow_head.conv2 kernel (v_pk_fma_f32 with a broadcast source half) returned
+    wrong values when another stream's fp16-MFMA waves shared the SIMD.  Those units are built with -fno-slp-vectorize; this test
+    disassembles the built library's gfx950 code objects and requires the kernels to be free of packed-fp32 arithmetic."""
+    import re
+    import shutil
+    import subprocess
+    from nndepth_amd._lib import LIB_PATH
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    lib = tmp_path / "lib.so"
+    shutil.copy(LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]
+    assert objs, "no gfx950 code object in the library"
+    seen = set()
+    for f in objs:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            if "flow_branch" in name or "flow_head2" in name:
+                seen.add(name)
+                packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", body)
+                assert not packed, f"{name}: {len(packed)} packed-fp32 instructions"
+    assert any("flow_branch_kernel" in n for n in seen) and any("flow_head2_kernel" in n for n in seen) and \
+        any("flow_branch_lookup_kernel" in n for n in seen), sorted(seen)

@@ -347,7 +347,8 @@ def test_two_host_threads_on_two_streams_equal_serial(raft_sd):
 def test_forward_is_reproducible_beside_another_streams_encoder(raft_sd):
     """Regression for a round-3 finding: with the fused flow-branch kernel sharing its CU with ANOTHER stream's kernels (the small
     workgroups of the fp16x2 encoder) 10-25 % of the forwards differed from the undisturbed result (a few sub-tiles of convf2's
-    output, ~1 % of the values).  The launch now owns its CU (csrc/conv_split.hip: launch_fb).  Victim: the RAFT-Stereo forward on
+    output, ~1 % of the values): its packed-fp32 FMAs next to another kernel's fp16 MFMA waves; the unit is now built
+    without them (csrc/Makefile: NOSLP).  Victim: the RAFT-Stereo forward on
     one stream, compared bit for bit with its undisturbed result; aggressor: a second host thread looping the fp16x2 encoder on
     another stream.  120 forwards (the unfixed kernel failed 30-90 of 400 on every box tried)."""
     import threading
@@ -390,7 +391,7 @@ def test_forward_is_reproducible_beside_another_streams_encoder(raft_sd):
 def test_cre_forward_is_reproducible_beside_another_streams_encoder(raft_sd, cre_sd):
     """The same for the CREStereo cascade (fp16x2 and exact fp32): its 2-channel `flow_head.conv2` kernel showed the same
     dependence on foreign workgroups sharing its CU (48-55 of 200 update-block steps with a different `delta`,
-    scripts/race_ub_buffers.py) and owns its CU as well (csrc/update_block.hip: run_fc2).  60 forwards per arithmetic."""
+    scripts/race_ub_buffers.py), same cause, same fix.  60 forwards per arithmetic."""
     import threading
     from nndepth_amd import weightgen
     from nndepth_amd.cre_stereo import CREStereoBase

@@ -348,7 +348,7 @@ def test_fused_flow_branch_is_bit_identical_to_two_launches(monkeypatch, fc, ari
 def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monkeypatch, raft_sd):
     """Round 3 (fp16x2, RAFT-Stereo): the motion encoder's flow branch and lookup + convc1 of an iteration run as ONE launch of two
     kinds of workgroups (corr1d.hip: flow_branch_lookup_kernel).  Same device code as the two kernels: against the two launches
-    (the default; the merged launch is NND_MERGED_FB_LOOKUP=1) every output of the loop must match bit for bit — ragged 13x22 map, batch 2, and the 96x160 forward."""
+    (NND_NO_MERGED_FB_LOOKUP) every output of the loop must match bit for bit — ragged 13x22 map, batch 2, and the 96x160 forward."""
     from nndepth_amd import weightgen
     from nndepth_amd.blocks import BasicUpdateBlock
     from nndepth_amd.cost_volume import CorrBlock1D
@@ -369,9 +369,8 @@ def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monke
         outs += [o["up_disp"].clone() for o in m.to(DEV).eval()(fr1.to(DEV), fr2.to(DEV))]
         return outs
 
-    monkeypatch.setenv("NND_MERGED_FB_LOOKUP", "1")  # opt-in: the default keeps the flow branch alone on its CU (csrc/conv_split.hip: launch_fb)
     a = run()
-    monkeypatch.delenv("NND_MERGED_FB_LOOKUP")
+    monkeypatch.setenv("NND_NO_MERGED_FB_LOOKUP", "1")
     b = run()
     assert len(a) == len(b) == 8
     for i, (x, y) in enumerate(zip(a, b)):
