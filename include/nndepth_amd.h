@@ -88,8 +88,9 @@ int nnd_corr1d_lookup(const float* pyramid, const float* coords, float* out,
  * uses only the first num_groups chunks of num_groups channels) and divides by sqrt(group_channels).
  * Pyramids use the layout of nnd_corr1d_pyramid_layout(B*num_groups, H, W, num_levels): rows ordered (b,g,h,w1),
  * so level 0 viewed as (B,G,H,W1,W2) is the tensor the 3-D regulariser (nnd_conv3d_*) consumes.
+ * num_levels = 0 writes level 0 alone (the fused refinement loop reads the interleaved copy below, which pools for itself).
  * nnd_pyramid_from_level0 fills levels 1..num_levels of a pyramid whose level 0 was written by the caller (the
- * regularised volume).  nnd_igev_lookup: coords (B,1,H,W) -> out (B, num_levels*2*G*(2r+1), H, W), channel
+ * regularised volume, or a feature volume built with num_levels = 0).  nnd_igev_lookup: coords (B,1,H,W) -> out (B, num_levels*2*G*(2r+1), H, W), channel
  * = i*2*G*T + v*G*T + g*T + k with v = 0 feature / 1 geometry volume.                                   */
 int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
                          int num_groups, int group_channels, int num_levels, void* stream);
@@ -103,6 +104,12 @@ int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const f
 int64_t nnd_igev_interleaved_floats(int B, int G, int H, int W, int num_levels);
 int nnd_igev_interleave_pyramids(const float* feat_pyramid, const float* geo_pyramid, float* interleaved,
                                  int B, int G, int H, int W, int num_levels, void* stream);
+/* The same interleaved levels from the two level-0 volumes alone (rows (b,g,h,w1) of W floats each): the avg_pool1d cascade
+ * of cost_volume.py:46-52 runs in LDS with the pyramid's arithmetic (bit-identical to pooling first), so neither pyramid's
+ * pooled levels have to exist.  _supported: 2*G <= 32, every level at least 1 wide, one pixel's levels within 160 KB of LDS. */
+int nnd_igev_interleave_level0_supported(int G, int W, int num_levels);
+int nnd_igev_interleave_level0(const float* feat_level0, const float* geo_level0, float* interleaved,
+                               int B, int G, int H, int W, int num_levels, void* stream);
 
 /* ------------------------------------------------- CREStereo adaptive group correlation (AGCL)
  * Replaces AGCL.corr_iter / get_correlation / corr_att_offset and bilinear_sampler / bilinear_grid_sample
@@ -361,7 +368,10 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
  * coords1 = arange(W) + disp_init + sum(delta), not the disparity.  disp_init = the soft-argmin initial disparity
  * (computed by the caller: Conv3d squeezer + softmax, PyTorch).  up_out / low_out hold coordinates accordingly.
  * interleaved: optional (may be NULL) output of nnd_igev_interleave_pyramids for the same pyramids; when given, the
- * per-iteration lookup gathers from it (same values, ~4x fewer HBM lines).                                        */
+ * per-iteration lookup gathers from it (same values, ~4x fewer HBM lines).  nnd_igev_refine_reads_interleaved = 1 when,
+ * given that copy, the loop reads nothing else of the two pyramids (groups / radius the fused lookup is built for and the
+ * fused lookup not switched off): their pooled levels may then be left unwritten.                                 */
+int nnd_igev_refine_reads_interleaved(int num_groups, int num_levels, int radius);
 int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed_dev,
                            const float* feat_pyramid, const float* geo_pyramid, const float* interleaved,
                            int num_groups, int num_levels, int radius,

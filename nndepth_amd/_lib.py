@@ -73,6 +73,9 @@ SIGNATURES = {
                                     _I, _I, _I, _I, _I, _P]),
     "nnd_igev_interleaved_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "nnd_igev_interleave_pyramids": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nnd_igev_interleave_level0_supported": (_I, [_I, _I, _I]),
+    "nnd_igev_refine_reads_interleaved": (_I, [_I, _I, _I]),
+    "nnd_igev_interleave_level0": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_igev_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
     "nnd_cre_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _I, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, _P, _P, _P,

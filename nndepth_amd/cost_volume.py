@@ -49,22 +49,56 @@ class GeometryAwareCostVolume:
         assert C % num_groups == 0, "Number of channels of fmap1 and fmap2 must be the factor of num_groups"
         self.shape = (B, H, W)
         # torch.split(fmap, num_groups) yields chunks of num_groups channels; only the first num_groups are used (Q4)
-        self._feat = ops.group_corr_build(fmap1.float(), fmap2.float(), num_groups, num_groups, num_levels)
-        feat0 = self._feat[:B * num_groups * H * W * W].view(B, num_groups, H, W, W)
-        if getattr(regularizer_3d, "hip_active", lambda x: False)(feat0):
+        hip_reg = getattr(regularizer_3d, "hip_active", None)
+        lazy = hip_reg is not None and ops.igev_interleave_level0_supported(num_groups, W, num_levels)
+        # lazy: level 0 of both volumes now, the pooled levels when somebody reads them — the fused loop does not (it gathers
+        # from interleaved(), which pools in LDS)
+        self._feat_buf = ops.group_corr_build(fmap1.float(), fmap2.float(), num_groups, num_groups, num_levels, pooled=not lazy)
+        self._pooled = not lazy
+        feat0 = self._feat_buf[:B * num_groups * H * W * W].view(B, num_groups, H, W, W)
+        if hip_reg is not None and hip_reg(feat0):
             # nndepth_amd's regulariser on its HIP path reads the rows of the feature volume and writes the rows of the
             # geometry volume straight into its pyramid buffer: no permuted copies either side
             _, _, total = ops.pyramid_layout(B * num_groups, H, W, num_levels)
-            self._geo = torch.empty(total, dtype=torch.float32, device=feat0.device)
-            regularizer_3d.forward_rows(feat0, features, out=self._geo[:feat0.numel()].view(B, num_groups, H, W, W))
-            ops.pyramid_pool_levels_(self._geo, B * num_groups, H, W, num_levels)
+            self._geo_buf = torch.empty(total, dtype=torch.float32, device=feat0.device)
+            regularizer_3d.forward_rows(feat0, features, out=self._geo_buf[:feat0.numel()].view(B, num_groups, H, W, W))
+            if self._pooled:
+                ops.pyramid_pool_levels_(self._geo_buf, B * num_groups, H, W, num_levels)
             return
+        if not self._pooled:
+            ops.pyramid_pool_levels_(self._feat_buf, B * num_groups, H, W, num_levels)
+            self._pooled = True
         geo = regularizer_3d(feat0.clone().permute(0, 1, 4, 2, 3), features)          # (B, G, W2, H, W1)
         geo0 = geo.permute(0, 1, 3, 4, 2).contiguous().float()                          # (B, G, H, W1, W2)
-        self._geo = ops.pyramid_from_level0(geo0.view(-1, W), B * num_groups, H, W, num_levels)
+        self._geo_buf = ops.pyramid_from_level0(geo0.view(-1, W), B * num_groups, H, W, num_levels)
+
+    @property
+    def _feat(self):  # the feature pyramid, all levels in place
+        return self.pyramids()[0]
+
+    @property
+    def _geo(self):
+        return self.pyramids()[1]
+
+    def pyramids(self, pooled: bool = True):
+        """(feature pyramid, geometry pyramid) buffers in ops.pyramid_layout; pooled=False: only their level 0 is promised."""
+        if pooled and not self._pooled:
+            B, H, W = self.shape
+            ops.pyramid_pool_levels_(self._feat_buf, B * self.num_groups, H, W, self.num_levels)
+            ops.pyramid_pool_levels_(self._geo_buf, B * self.num_groups, H, W, self.num_levels)
+            self._pooled = True
+        return self._feat_buf, self._geo_buf
+
+    @property
+    def geo_level0(self) -> torch.Tensor:
+        """`geo_aware_cv[0]` without asking for the pooled levels."""
+        B, H, W = self.shape
+        n = B * self.num_groups * H * W
+        return self._geo_buf[:n * W].view(n, 1, W)
 
     def _views(self, pyr):
         B, H, W = self.shape
+        self.pyramids()
         n = B * self.num_groups * H * W
         offs, widths, _ = ops.pyramid_layout(B * self.num_groups, H, W, self.num_levels)
         return [pyr[o:o + n * w].view(n, 1, w) for o, w in zip(offs, widths)]
@@ -73,19 +107,22 @@ class GeometryAwareCostVolume:
         """Both pyramids in the group-interleaved layout the fused refinement loop gathers from (built on first use)."""
         if getattr(self, "_il", None) is None:
             B, H, W = self.shape
-            self._il = ops.igev_interleave_pyramids(self._feat, self._geo, B, self.num_groups, H, W, self.num_levels)
+            if ops.igev_interleave_level0_supported(self.num_groups, W, self.num_levels):
+                self._il = ops.igev_interleave_level0(self._feat_buf, self._geo_buf, B, self.num_groups, H, W, self.num_levels)
+            else:
+                self._il = ops.igev_interleave_pyramids(*self.pyramids(), B, self.num_groups, H, W, self.num_levels)
         return self._il
 
     @property
     def feat_corr_cv(self):
-        return self._views(self._feat)
+        return self._views(self._feat_buf)
 
     @property
     def geo_aware_cv(self):
-        return self._views(self._geo)
+        return self._views(self._geo_buf)
 
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
-        return ops.igev_lookup(self._feat, self._geo, coords.float(), self.num_groups, self.num_levels, self.radius)
+        return ops.igev_lookup(*self.pyramids(), coords.float(), self.num_groups, self.num_levels, self.radius)
 
     forward = __call__
 

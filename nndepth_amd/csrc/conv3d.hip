@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) rows_depth_major_kernel(const float* __re
 
 // ATen compute_source_index_and_lambda for align_corners = true: real = scale * dst, scale = (in - 1) / (out - 1)
 __device__ __forceinline__ void src_index_ac(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
+#pragma clang fp contract(off)  // the product is rounded before the subtraction as in ATen: contracted into an FMA, the weight would carry up to half an ulp of `real` (4e-6 at 120; HIP's __fmul_rn is a plain product and does not prevent it)
     const float real = scale * (float)dst;
     i0 = min((int)floorf(real), in_size - 1);
     l1 = fminf(fmaxf(real - (float)i0, 0.f), 1.f);
@@ -126,16 +127,21 @@ __device__ __forceinline__ void src_index_ac(float scale, int dst, int in_size, 
 // (n, slice, channel) plane: the <= UP_R/2+2 source rows of the two source slices are staged in LDS with coalesced loads
 // (0.8 global loads per output instead of 8 cached gathers, which made the kernel texture-address bound), then every
 // output takes its 8 taps from LDS with ATen's weights and summation order (thread = output column, rows looped).
-constexpr int UP_R = 8, UP_SR = UP_R / 2 + 2;
+// A band of UP_R = 32 output rows per workgroup (8 when the staged rows would not fit 64 KB of LDS): a workgroup's life is the
+// serial chain load -> barrier -> 8 LDS taps per output -> store, and with 8-row bands (7.7 KB written per workgroup, 131 k
+// workgroups per sample at 120x68x120) the kernel was bound by that chain's latency, not by HBM (1.6 TB/s); thread = two
+// adjacent output columns (one 8-byte store).
+template <int UP_R>
 __global__ void __launch_bounds__(256) trilinear_up2_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int D, int H,
                                                             int W) {
+    constexpr int UP_SR = UP_R / 2 + 2;
     extern __shared__ float sm[];  // [2 slices][UP_SR rows][W]
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const int oy0 = blockIdx.x * UP_R, nrow = min(UP_R, Ho - oy0);
     const int c = blockIdx.y % C, dp = blockIdx.y / C, n = blockIdx.z;  // dp: padded output slice 0..Do+1
     float* o = y + ((((long)n * (Do + 2) + dp) * C + c) * Ho + oy0) * Wo;
     if (dp == 0 || dp == Do + 1) {
-        for (int i = threadIdx.x; i < nrow * Wo; i += 256) o[i] = 0.f;
+        for (int i = threadIdx.x; i < nrow * W; i += 256) reinterpret_cast<float2*>(o)[i] = make_float2(0.f, 0.f);
         return;
     }
     int d0, d1, ys, yt;
@@ -146,31 +152,34 @@ __global__ void __launch_bounds__(256) trilinear_up2_kernel(const float* __restr
     const long HW = (long)H * W;
     const float* p0 = x + (((long)n * (D + 2) + d0 + 1) * C + c) * HW;
     const float* p1 = x + (((long)n * (D + 2) + d1 + 1) * C + c) * HW;
-#pragma unroll
-    for (int r = 0; r < 2 * UP_SR; ++r) {  // row r of slice r / UP_SR
-        const float* src = (r < UP_SR ? p0 : p1) + (long)min(ys + (r % UP_SR), H - 1) * W;
-        for (int xx = threadIdx.x; xx < W; xx += 256) sm[r * W + xx] = src[xx];
+    const int nsr = min(UP_SR, nrow / 2 + 2);  // source rows the band can touch
+    for (int i = threadIdx.x; i < 2 * nsr * W; i += 256) {
+        const int r = i / W, xx = i - r * W, sl = r / nsr, rr = r - sl * nsr;
+        sm[(sl * UP_SR + rr) * W + xx] = (sl ? p1 : p0)[(long)min(ys + rr, H - 1) * W + xx];
     }
     __syncthreads();
-    // thread = output column (its x taps are fixed); the row loop is wave-uniform, so the y taps cost scalar work only
-    // (narrow planes: 256 / Wo row groups share the block, group rg takes rows rg, rg + nrg, ...)
-    const int nrg = Wo < 256 ? 256 / Wo : 1, rg = Wo < 256 ? (int)threadIdx.x / Wo : 0;
-    for (int ox = Wo < 256 ? (int)threadIdx.x % Wo : (int)threadIdx.x; ox < Wo && rg < nrg; ox += 256) {
-        int x0, x1;
-        float lx0, lx1;
-        src_index_ac(sx, ox, W, x0, x1, lx0, lx1);
+    // thread = a pair of output columns (their x taps are fixed); narrow planes: 256 / W row groups share the block
+    const int nrg = W < 256 ? 256 / W : 1, rg = W < 256 ? (int)threadIdx.x / W : 0;
+    for (int op = W < 256 ? (int)threadIdx.x % W : (int)threadIdx.x; op < W && rg < nrg; op += 256) {
+        int xa0, xa1, xb0, xb1;
+        float la0, la1, lb0, lb1;
+        src_index_ac(sx, 2 * op, W, xa0, xa1, la0, la1);
+        src_index_ac(sx, 2 * op + 1, W, xb0, xb1, lb0, lb1);
         for (int r = rg; r < nrow; r += nrg) {
             int y0, y1;
             float ly0, ly1;
             src_index_ac(sy, oy0 + r, H, y0, y1, ly0, ly1);
             const float* r0 = sm + (y0 - ys) * W;
             const float* r1 = sm + (y1 - ys) * W;
-            auto plane = [&](const float* a, const float* b) {
+            auto plane = [&](const float* a, const float* b, int x0, int x1, float lx0, float lx1) {
                 const float t0 = lx0 * a[x0] + lx1 * a[x1];
                 const float t1 = lx0 * b[x0] + lx1 * b[x1];
                 return ly0 * t0 + ly1 * t1;
             };
-            o[r * Wo + ox] = ld0 * plane(r0, r1) + ld1 * plane(r0 + UP_SR * W, r1 + UP_SR * W);
+            float2 v;
+            v.x = ld0 * plane(r0, r1, xa0, xa1, la0, la1) + ld1 * plane(r0 + UP_SR * W, r1 + UP_SR * W, xa0, xa1, la0, la1);
+            v.y = ld0 * plane(r0, r1, xb0, xb1, lb0, lb1) + ld1 * plane(r0 + UP_SR * W, r1 + UP_SR * W, xb0, xb1, lb0, lb1);
+            *reinterpret_cast<float2*>(o + r * Wo + 2 * op) = v;
         }
     }
 }
@@ -397,9 +406,13 @@ int nnd_depth_major_to_volume_rows(const float* x, float* y, int N, int C, int D
 
 int nnd_volume_upsample2x(const float* x, float* y, int N, int C, int D, int H, int W, void* stream) {
     NND_REQUIRE(x && y && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (long)C * (2 * D + 2) <= 65535, "volume_upsample2x: bad argument");
-    NND_REQUIRE((size_t)2 * UP_SR * W * sizeof(float) <= 64 * 1024, "volume_upsample2x: rows of %d floats do not fit the LDS staging", W);
-    hipLaunchKernelGGL(trilinear_up2_kernel, dim3(cdiv(2 * H, UP_R), C * (2 * D + 2), N), dim3(256), 2 * UP_SR * W * sizeof(float),
-                       (hipStream_t)stream, x, y, C, D, H, W);
+    NND_REQUIRE((size_t)2 * 6 * W * sizeof(float) <= 64 * 1024, "volume_upsample2x: rows of %d floats do not fit the LDS staging", W);
+    if ((size_t)2 * 18 * W * sizeof(float) <= 64 * 1024)
+        hipLaunchKernelGGL(trilinear_up2_kernel<32>, dim3(cdiv(2 * H, 32), C * (2 * D + 2), N), dim3(256), 2 * 18 * W * sizeof(float),
+                           (hipStream_t)stream, x, y, C, D, H, W);
+    else
+        hipLaunchKernelGGL(trilinear_up2_kernel<8>, dim3(cdiv(2 * H, 8), C * (2 * D + 2), N), dim3(256), 2 * 6 * W * sizeof(float),
+                           (hipStream_t)stream, x, y, C, D, H, W);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

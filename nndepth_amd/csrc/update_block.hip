@@ -944,6 +944,10 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
                           net_out, workspace, B, H, W, rate, iters, stream);
 }
 
+int nnd_igev_refine_reads_interleaved(int num_groups, int num_levels, int radius) {
+    return !switches().no_fused_lookup && igev_lookup_convc1_il_supported(num_groups, num_levels, radius);
+}
+
 int nnd_igev_stereo_refine(const nnd_update_block_desc* desc, const float* packed, const float* feat_pyramid,
                            const float* geo_pyramid, const float* interleaved, int num_groups, int num_levels, int radius,
                            const float* net, const float* inp,

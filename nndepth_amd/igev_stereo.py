@@ -223,7 +223,7 @@ class IGEVStereoBase(nn.Module):
                             self.cv_groups)
         B, _, H1, W1 = fmap1.shape
         W2 = fmap2.shape[-1]
-        geo0 = corr.geo_aware_cv[0]
+        geo0 = corr.geo_level0 if hasattr(corr, "geo_level0") else corr.geo_aware_cv[0]  # model.py:144
         if ops.igev_init_disparity_supported(self.cv_groups, W2):
             # cv_squeezer + softmax + regress_disparity as one kernel over the volume where it lies
             init = ops.igev_init_disparity(geo0, *self._squeezer_host(), B, self.cv_groups, H1, W1, W2)
@@ -237,9 +237,13 @@ class IGEVStereoBase(nn.Module):
             init = ops.softargmin_disparity(logits.float())
         if self.fused_loop and isinstance(corr, GeometryAwareCostVolume):
             eng = self.update_block.sync_engine(frame1.device)
-            up, low, _ = eng.refine_igev(corr._feat, corr._geo, self.cv_groups, self.corr_levels, self.corr_radius,
+            il = corr.interleaved()
+            # the loop gathers from the interleaved copy alone when its fused lookup is built for these groups / radius:
+            # the pooled levels of the two pyramids are then never made
+            feat, geo = corr.pyramids(pooled=not ops.igev_refine_reads_interleaved(self.cv_groups, self.corr_levels, self.corr_radius))
+            up, low, _ = eng.refine_igev(feat, geo, self.cv_groups, self.corr_levels, self.corr_radius,
                                          net.float(), inp.float(), fnet_ds, self.iters, disp_init=init, keep_all=True,
-                                         interleaved=corr.interleaved())
+                                         interleaved=il)
             self.last_low_coords = low  # the loop's state after the last iteration: absolute coordinates at 1/4 resolution (Q5)
             return [{"up_disp": up[i]} for i in range(self.iters)]
         coords1 = self.initialize_coords(fmap1) + init

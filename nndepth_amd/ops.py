@@ -406,8 +406,9 @@ class UpdateBlockEngine:
 
 # ------------------------------------------------------------------ IGEV geometry-encoding volume
 def group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, group_channels: int,
-                     num_levels: int) -> torch.Tensor:
-    """Group-wise 1-D correlation pyramid; layout = pyramid_layout(B*num_groups, H, W, num_levels)."""
+                     num_levels: int, pooled: bool = True) -> torch.Tensor:
+    """Group-wise 1-D correlation pyramid; layout = pyramid_layout(B*num_groups, H, W, num_levels).
+    pooled=False: the buffer has that layout but only level 0 is written (pyramid_pool_levels_ fills the rest on demand)."""
     d = _dev(fmap1, fmap2)
     fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
     B, Ctot, H, W = fmap1.shape
@@ -415,7 +416,7 @@ def group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, 
     pyr = torch.empty(total, dtype=torch.float32, device=d)
     with torch.cuda.device(d):
         check(lib.nnd_group_corr_build(_p(fmap1), _p(fmap2), _p(pyr), B, Ctot, H, W, num_groups, group_channels,
-                                       num_levels, _stream(d)), "group_corr_build")
+                                       num_levels if pooled else 0, _stream(d)), "group_corr_build")
     return pyr
 
 
@@ -458,6 +459,30 @@ def igev_interleave_pyramids(feat_pyr: torch.Tensor, geo_pyr: torch.Tensor, B: i
     with torch.cuda.device(d):
         check(lib.nnd_igev_interleave_pyramids(_p(feat_pyr), _p(geo_pyr), _p(out), B, num_groups, H, W, num_levels,
                                                _stream(d)), "igev_interleave_pyramids")
+    return out
+
+
+def igev_refine_reads_interleaved(num_groups: int, num_levels: int, radius: int) -> bool:
+    """True when nnd_igev_stereo_refine, given an interleaved copy, never reads the plain pyramids (their pooled levels
+    need not exist)."""
+    return bool(lib.nnd_igev_refine_reads_interleaved(num_groups, num_levels, radius))
+
+
+def igev_interleave_level0_supported(num_groups: int, W: int, num_levels: int) -> bool:
+    return bool(lib.nnd_igev_interleave_level0_supported(num_groups, W, num_levels))
+
+
+def igev_interleave_level0(feat_level0: torch.Tensor, geo_level0: torch.Tensor, B: int, num_groups: int, H: int, W: int,
+                           num_levels: int) -> torch.Tensor:
+    """The interleaved levels 0..num_levels-1 from the two level-0 volumes (pooling in LDS; same values as pooling both
+    pyramids and igev_interleave_pyramids).  The tensors may be whole pyramid buffers: only their level 0 is read."""
+    d = _dev(feat_level0, geo_level0)
+    n0 = B * num_groups * H * W * W
+    assert feat_level0.numel() >= n0 and geo_level0.numel() >= n0 and feat_level0.is_contiguous() and geo_level0.is_contiguous()
+    out = torch.empty(lib.nnd_igev_interleaved_floats(B, num_groups, H, W, num_levels), dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_igev_interleave_level0(_p(feat_level0), _p(geo_level0), _p(out), B, num_groups, H, W, num_levels,
+                                             _stream(d)), "igev_interleave_level0")
     return out
 
 

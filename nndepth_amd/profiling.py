@@ -85,16 +85,21 @@ def igev_rows(dev, B: int = 1, G: int = 8, H: int = 136, W: int = 240) -> List[D
     rows = []
     f1, f2 = f(B, 128, H, W), f(B, 128, H, W)
     fp = ops.group_corr_build(f1, f2, G, G, 4)
-    rows.append(_row(f"group_corr_build {H}x{W} G={G}", time_us(lambda: ops.group_corr_build(f1, f2, G, G, 4), 12),
+    n0 = B * G * H * W * W
+    rows.append(_row(f"group_corr_build {H}x{W} G={G}, level 0 (the model's call)", time_us(lambda: ops.group_corr_build(f1, f2, G, G, 4, pooled=False), 12),
+                     (2 * B * 64 * H * W + n0) * 4 / 1e6, "64 ch of 2 fmaps read + level 0 written"))
+    rows.append(_row(f"group_corr_build {H}x{W} G={G}, 5 levels", time_us(lambda: ops.group_corr_build(f1, f2, G, G, 4), 12),
                      (2 * B * 64 * H * W + fp.numel()) * 4 / 1e6, "64 ch of 2 fmaps read + 5 levels written"))
     gp = fp.clone()
-    rows.append(_row(f"pyramid_pool_levels {H}x{W} G={G}", time_us(lambda: ops.pyramid_pool_levels_(gp, B * G, H, W, 4), 12),
+    rows.append(_row(f"pyramid_pool_levels {H}x{W} G={G} (on demand only)", time_us(lambda: ops.pyramid_pool_levels_(gp, B * G, H, W, 4), 12),
                      (2 * fp.numel() - B * G * H * W * W) * 4 / 1e6, "levels 0-3 read, levels 1-4 written"))
     coords = torch.arange(W, device=dev).float().view(1, 1, 1, W).repeat(B, 1, H, 1) - 20 * torch.rand(B, 1, H, W, device=dev)
     rows.append(_row(f"igev_lookup {H}x{W} (576 ch)", time_us(lambda: ops.igev_lookup(fp, gp, coords, G, 4, 4), 20),
                      (3 * 576 + 1) * B * H * W * 4 / 1e6, "2 taps x 576 samples read + 576 ch written"))
     il = ops.igev_interleave_pyramids(fp, gp, B, G, H, W, 4)
-    rows.append(_row(f"igev_interleave_pyramids {H}x{W} G={G}", time_us(lambda: ops.igev_interleave_pyramids(fp, gp, B, G, H, W, 4), 12),
+    rows.append(_row(f"igev_interleave_level0 {H}x{W} G={G} (the model's call)", time_us(lambda: ops.igev_interleave_level0(fp, gp, B, G, H, W, 4), 12),
+                     (2 * n0 + il.numel()) * 4 / 1e6, "level 0 of both volumes read, 4 interleaved levels written"))
+    rows.append(_row(f"igev_interleave_pyramids {H}x{W} G={G} (from pooled pyramids)", time_us(lambda: ops.igev_interleave_pyramids(fp, gp, B, G, H, W, 4), 12),
                      2 * il.numel() * 4 / 1e6, "levels 0-3 of both pyramids read + written"))
     conv = torch.nn.Conv3d(G, 1, 3, 1, 1)
     geo0 = gp[:B * G * H * W * W]

@@ -651,6 +651,29 @@ def test_igev_refine_loop_vs_oracle(R, B, H, W):
     assert o_il == il.numel()
 
 
+@pytest.mark.parametrize("B,G,H,W,levels", [(1, 8, 12, 64, 4), (2, 8, 5, 22, 3), (1, 8, 6, 45, 4), (2, 4, 7, 36, 4), (1, 3, 4, 31, 2),
+                                            (1, 8, 3, 240, 4)])
+def test_igev_interleave_from_level0_equals_pool_then_interleave(ops, B, G, H, W, levels):
+    """nnd_igev_interleave_level0 (avg_pool1d cascade of cost_volume.py:46-52 in LDS, then the interleaved layout) against the
+    two-step route — pooled pyramids (equal to F.avg_pool1d, test above) + nnd_igev_interleave_pyramids: bit for bit, vector and
+    scalar variants (W % 4, odd group counts), odd widths on the way down (45 -> 22 -> 11 -> 5), batch > 1.  And level 0 alone
+    from nnd_group_corr_build(num_levels = 0) == level 0 of the full build."""
+    g = torch.Generator().manual_seed(W * 131 + G)
+    n0 = B * G * H * W * W
+    f0, g0 = torch.randn(n0, generator=g).to(DEV), torch.randn(n0, generator=g).to(DEV)
+    fp = ops.pyramid_from_level0(f0.view(-1, W), B * G, H, W, levels)
+    gp = ops.pyramid_from_level0(g0.view(-1, W), B * G, H, W, levels)
+    want = ops.igev_interleave_pyramids(fp, gp, B, G, H, W, levels)
+    assert ops.igev_interleave_level0_supported(G, W, levels)
+    got = ops.igev_interleave_level0(f0, g0, B, G, H, W, levels)
+    assert got.shape == want.shape and torch.equal(got, want)
+    f1, f2 = torch.randn(B, 2 * G * G, H, W, generator=g).to(DEV), torch.randn(B, 2 * G * G, H, W, generator=g).to(DEV)
+    full = ops.group_corr_build(f1, f2, G, G, levels)
+    lvl0 = ops.group_corr_build(f1, f2, G, G, levels, pooled=False)
+    assert torch.equal(lvl0[:n0], full[:n0])
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------ CREStereo AGCL + sampler (a17-a19)
 @pytest.fixture(scope="module")
 def CR():
@@ -1137,6 +1160,17 @@ def test_volume_upsample_and_gate_vs_torch(ops):
     ops.volume_gate_(vol, logits.to(DEV))
     assert vol[:, 0].abs().max() == 0 and vol[:, -1].abs().max() == 0
     assert (ops.depth_major_to_volume(vol).cpu() - torch.sigmoid(logits).unsqueeze(2) * x).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4, 40, 130), (1, 2, 3, 17, 300), (2, 2, 5, 33, 31), (1, 1, 2, 20, 460)])
+def test_volume_upsample_row_bands_vs_torch(ops, shape):
+    """Several 32-row bands with a ragged last one (2H = 80, 34, 66), planes wider than the workgroup (2W = 260, 600), two row
+    groups per workgroup (W = 31), and the 8-row-band variant for rows too wide for 64 KB of staging (W = 460)."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    ref = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="trilinear", align_corners=True)
+    got = ops.depth_major_to_volume(ops.volume_upsample2x(ops.volume_to_depth_major(x.to(DEV)))).cpu()
+    assert got.shape == ref.shape and (got - ref).abs().max() <= 2e-6
 
 
 @pytest.mark.parametrize("name,B,H,W", [("g8_c128", 1, 8, 24), ("g8_c64_b2", 2, 8, 32)])
