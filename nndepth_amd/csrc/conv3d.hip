@@ -153,9 +153,28 @@ __global__ void __launch_bounds__(256) trilinear_up2_kernel(const float* __restr
     const float* p0 = x + (((long)n * (D + 2) + d0 + 1) * C + c) * HW;
     const float* p1 = x + (((long)n * (D + 2) + d1 + 1) * C + c) * HW;
     const int nsr = min(UP_SR, nrow / 2 + 2);  // source rows the band can touch
-    for (int i = threadIdx.x; i < 2 * nsr * W; i += 256) {
-        const int r = i / W, xx = i - r * W, sl = r / nsr, rr = r - sl * nsr;
-        sm[(sl * UP_SR + rr) * W + xx] = (sl ? p1 : p0)[(long)min(ys + rr, H - 1) * W + xx];
+    {  // staging: UP_LD loads in flight per thread before their LDS stores (one load per round trip left the kernel bound by load
+       // latency: ~17 serial round trips per workgroup); (row, column) of element i = tid + 256 k advance without divisions
+        constexpr int UP_LD = 9;
+        const int total = 2 * nsr * W, qs = 256 / W, ms = 256 - qs * W;
+        int r = (int)threadIdx.x / W, xx = (int)threadIdx.x - r * W;
+        for (int base = threadIdx.x; base < total; base += 256 * UP_LD) {
+            float v[UP_LD];
+            int dsti[UP_LD];
+#pragma unroll
+            for (int k = 0; k < UP_LD; ++k) {
+                const bool in = base + 256 * k < total;
+                const int sl = r >= nsr, rr = r - sl * nsr;
+                dsti[k] = in ? (sl * UP_SR + rr) * W + xx : -1;
+                v[k] = in ? (sl ? p1 : p0)[(long)min(ys + rr, H - 1) * W + xx] : 0.f;
+                xx += ms;
+                r += qs;
+                if (xx >= W) xx -= W, ++r;
+            }
+#pragma unroll
+            for (int k = 0; k < UP_LD; ++k)
+                if (dsti[k] >= 0) sm[dsti[k]] = v[k];
+        }
     }
     __syncthreads();
     // thread = a pair of output columns (their x taps are fixed); narrow planes: 256 / W row groups share the block

@@ -722,11 +722,27 @@ __global__ void __launch_bounds__(256) igev_pool_interleave_kernel(const float* 
     const long bp = blockIdx.x, b = bp / HW, pix = bp - b * HW;
     const int S0 = il_pool_stride(w2);
     if (V4) {
-        const int q4 = w2 >> 2;
-        for (int i = tid; i < VG * q4; i += 256) {
-            const int vg = i / q4, x4 = i - vg * q4, v = vg / G, g = vg - v * G;
-            const float* row = (v ? geo0 : feat0) + ((b * G + g) * HW + pix) * w2;
-            *reinterpret_cast<float4*>(sm + vg * S0 + 4 * x4) = *reinterpret_cast<const float4*>(row + 4 * x4);
+        // IL_LD loads in flight per thread before their LDS stores; (row, quad) of unit tid + 256 k advance without divisions
+        constexpr int IL_LD = 4;
+        const int q4 = w2 >> 2, total = VG * q4, qs = 256 / q4, ms = 256 - qs * q4;
+        int vg = tid / q4, x4 = tid - vg * q4;
+        for (int base = tid; base < total; base += 256 * IL_LD) {
+            float4 val[IL_LD];
+            int dsti[IL_LD];
+#pragma unroll
+            for (int k = 0; k < IL_LD; ++k) {
+                const bool in = base + 256 * k < total;
+                const int v = vg >= G, g = vg - v * G;
+                dsti[k] = in ? vg * S0 + 4 * x4 : -1;
+                val[k] = in ? *reinterpret_cast<const float4*>((v ? geo0 : feat0) + ((b * G + g) * HW + pix) * w2 + 4 * x4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                x4 += ms;
+                vg += qs;
+                if (x4 >= q4) x4 -= q4, ++vg;
+            }
+#pragma unroll
+            for (int k = 0; k < IL_LD; ++k)
+                if (dsti[k] >= 0) *reinterpret_cast<float4*>(sm + dsti[k]) = val[k];
         }
     } else {
         for (int i = tid; i < VG * w2; i += 256) {

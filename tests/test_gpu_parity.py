@@ -972,9 +972,11 @@ def test_igev_softargmin_vs_oracle(ops, R):
 
 def test_igev_squeezer_init_vs_oracle(ops, R):
     """cv_squeezer Conv3d(G,1,3,1,1) + soft-argmin fused (nnd_igev_init_disparity) vs the PyTorch CPU ops of the reference
-    (igev_stereo/model.py:144-146), incl. ragged widths, one candidate per thread and two (D > 256), G < 8."""
+    (igev_stereo/model.py:144-146), incl. ragged widths, one candidate per thread and two (D > 256), G < 8, more image rows than XCD bands
+    (H = 17) and a single row."""
     torch.manual_seed(14)
-    for (B, G, H, W, D, amp) in ((2, 8, 9, 21, 21, 1.0), (1, 8, 5, 13, 300, 0.5), (1, 3, 4, 8, 7, 2.0), (1, 8, 3, 17, 240, 1.0)):
+    for (B, G, H, W, D, amp) in ((2, 8, 9, 21, 21, 1.0), (1, 8, 5, 13, 300, 0.5), (1, 3, 4, 8, 7, 2.0), (1, 8, 3, 17, 240, 1.0),
+                                 (1, 8, 17, 10, 32, 1.0), (1, 8, 1, 9, 16, 1.0)):
         geo = torch.randn(B, G, H, W, D) * amp
         conv = torch.nn.Conv3d(G, 1, 3, 1, 1)
         with torch.no_grad():
