@@ -1164,6 +1164,22 @@ def test_volume_upsample_and_gate_vs_torch(ops):
     assert (ops.depth_major_to_volume(vol).cpu() - torch.sigmoid(logits).unsqueeze(2) * x).abs().max() <= 1e-6
 
 
+@pytest.mark.parametrize("N,C,H,W,D", [(1, 2, 5, 7, 9), (2, 3, 9, 15, 70), (1, 8, 8, 24, 64), (1, 1, 13, 10, 129)])
+def test_volume_rows_and_depth_major_layouts(ops, N, C, H, W, D):
+    """(N,C,H,W,D) rows <-> (N,D+2,C,H,W) depth-major with zero end slices (the regulariser's way in and out of the pyramids'
+    layout): exact copies, ragged 64x64 tiles on both axes (H*W = 35, 135, 130; D = 9, 70, 129) and exact ones."""
+    g = torch.Generator().manual_seed(N * 1000 + D)
+    x = torch.randn(N, C, H, W, D, generator=g)
+    dm = ops.volume_rows_to_depth_major(x.to(DEV))
+    want = torch.zeros(N, D + 2, C, H, W)
+    want[:, 1:-1] = x.permute(0, 4, 1, 2, 3)
+    assert torch.equal(dm.cpu(), want)
+    assert torch.equal(ops.depth_major_to_volume_rows(dm).cpu(), x)
+    out = torch.full((N * C * H * W * D + 5,), 7.0, device=DEV)
+    ops.depth_major_to_volume_rows(dm, out[:N * C * H * W * D].view(N, C, H, W, D))
+    assert torch.equal(out[:-5].cpu(), x.reshape(-1)) and bool((out[-5:] == 7.0).all())
+
+
 @pytest.mark.parametrize("shape", [(1, 3, 4, 40, 130), (1, 2, 3, 17, 300), (2, 2, 5, 33, 31), (1, 1, 2, 20, 460)])
 def test_volume_upsample_row_bands_vs_torch(ops, shape):
     """Several 32-row bands with a ragged last one (2H = 80, 34, 66), planes wider than the workgroup (2W = 260, 600), two row
