@@ -254,8 +254,15 @@ __global__ void __launch_bounds__(256) corr1d_build_lds_kernel(const float* __re
     lo = 0;
     for (int l = 0; l < L.nlev; ++l) {
         const int wl = L.width[l];
-        float* g = pyr + L.off[l] + prow0 * wl;
-        for (int idx = tid; idx < nrows * wl; idx += 256) g[idx] = sm[lo + idx];
+        const long g0 = L.off[l] + prow0 * wl;
+        float* g = pyr + g0;
+        const int cnt = nrows * wl;
+        if (((g0 | cnt) & 3) == 0) {  // the block's rows of a level are one contiguous run: 16-byte stores when it is aligned
+            for (int idx = tid; idx < cnt >> 2; idx += 256)
+                reinterpret_cast<float4*>(g)[idx] = *reinterpret_cast<const float4*>(sm + lo + 4 * idx);
+        } else {
+            for (int idx = tid; idx < cnt; idx += 256) g[idx] = sm[lo + idx];
+        }
         lo += 32 * wl;
     }
 }

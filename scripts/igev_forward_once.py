@@ -1,4 +1,4 @@
-"""Three IGEV forwards at 544x960 batch 1 (config 3, test backbone, fp16x2) for rocprofv3 --kernel-trace (scripts/prof_igev_forward.sh)."""
+"""Three IGEV forwards at 544x960 batch 1 (config 3, test backbone, fp16x2) for rocprofv3 --kernel-trace (scripts/prof_forward_kernels.sh)."""
 import os
 import sys
 
