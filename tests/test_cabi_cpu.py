@@ -272,7 +272,9 @@ def test_no_packed_fp32_fma_in_the_update_blocks_valu_convolutions(tmp_path):
     """Round-3 finding (profiles/r03_flow_branch_coresidency.txt): the packed-fp32 FMAs the SLP vectoriser formed in
     the fused flow-branch kernel and in the 2-channel flow_head.conv2 kernel (v_pk_fma_f32 with a broadcast source half) returned
     wrong values when another stream's fp16-MFMA waves shared the SIMD.  Those units are built with -fno-slp-vectorize; this test
-    disassembles the built library's gfx950 code objects and requires the kernels to be free of packed-fp32 arithmetic."""
+    disassembles the built library's gfx950 code objects and requires (i) the two kernels to be free of packed-fp32 arithmetic and
+    (ii) NO kernel of the library to hold the instruction with that signature — v_pk_fma_f32 with an `op_sel:[...]` modifier, i.e.
+    a register operand whose halves are swapped or broadcast (csrc/Makefile: the units where the vectoriser had formed it)."""
     import re
     import shutil
     import subprocess
@@ -294,5 +296,7 @@ def test_no_packed_fp32_fma_in_the_update_blocks_valu_convolutions(tmp_path):
                 seen.add(name)
                 packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", body)
                 assert not packed, f"{name}: {len(packed)} packed-fp32 instructions"
+            bcast = re.findall(r"v_pk_fma_f32[^\n]* op_sel:\[", body)
+            assert not bcast, f"{name}: {len(bcast)} packed-fp32 FMAs with swapped / broadcast operand halves"
     assert any("flow_branch_kernel" in n for n in seen) and any("flow_head2_kernel" in n for n in seen) and \
         any("flow_branch_lookup_kernel" in n for n in seen), sorted(seen)
