@@ -413,6 +413,13 @@ int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed
                           int num_levels, int radius, const float* net, const float* inp, float* up_out,
                           float* workspace, int B, int H, int W, int rate, int iters, int which, void* stream,
                           float* ms_out);
+/* Calibration of the above: the same loop with BOTH events of every iteration recorded in front of conv `which`, nothing
+ * between them.  *ms_out = what an event pair alone measures at that place of the stream (the part of nnd_profile_loop_conv's
+ * figure that is not the launch): bench.py reports it beside the raw figure.                                         */
+int nnd_profile_loop_event_pair(const nnd_update_block_desc* desc, const float* packed_dev, const float* pyramid,
+                                int num_levels, int radius, const float* net, const float* inp, float* up_out,
+                                float* workspace, int B, int H, int W, int rate, int iters, int which, void* stream,
+                                float* ms_out);
 /* Diagnostic: sustained fp32-MFMA rate of this device (dependent v_mfma_f32_32x32x2 chains, no memory
  * traffic) at `waves_per_simd` resident waves; `scratch_dev` is any device buffer of >= 1 float.        */
 int nnd_profile_mfma_peak(int waves_per_simd, int iters, void* stream, float* scratch_dev, float* tflops_out);

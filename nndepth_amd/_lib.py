@@ -109,6 +109,8 @@ SIGNATURES = {
                               C.POINTER(C.c_double)]),
     "nnd_profile_loop_conv": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P,
                                    C.POINTER(C.c_float)]),
+    "nnd_profile_loop_event_pair": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P,
+                                         C.POINTER(C.c_float)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),
     "nnd_reload_switches": (_I, []),
     "nnd_num_convs": (_I, [C.POINTER(UpdateBlockDesc)]),

@@ -709,15 +709,21 @@ struct CreArgs {
 // iteration of the fused loop brackets conv `which` on the caller's stream with a pair of timing events.
 struct LoopProbe {
     int which;
+    bool empty = false;          // calibration run: both events in FRONT of the conv, nothing between them
+    int marks = 0;
     std::vector<hipEvent_t> ev;  // 2 per iteration
 };
 static thread_local LoopProbe* t_probe = nullptr;
 static void probe_mark(int id, hipStream_t s) {
     if (!t_probe || t_probe->which != id) return;
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return;
-    (void)hipEventRecord(e, s);
-    t_probe->ev.push_back(e);
+    const bool opening = (t_probe->marks++ & 1) == 0;
+    if (t_probe->empty && !opening) return;
+    for (int k = 0; k < (t_probe->empty ? 2 : 1); ++k) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, s);
+        t_probe->ev.push_back(e);
+    }
 }
 
 // geo_pyramid != nullptr selects the IGEV variant: combined two-volume lookup over `groups` groups and
@@ -1026,13 +1032,14 @@ int nnd_profile_conv(const nnd_update_block_desc* desc, const float* packed, flo
 }
 }
 
-extern "C" int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
-                                     int radius, const float* net, const float* inp, float* up_out, float* workspace, int B, int H,
-                                     int W, int rate, int iters, int which, void* stream, float* ms_out) {
+static int profile_loop(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels, int radius,
+                        const float* net, const float* inp, float* up_out, float* workspace, int B, int H, int W, int rate, int iters,
+                        int which, void* stream, float* ms_out, bool empty) {
     NND_REQUIRE(ms_out && which >= 0 && which < C_LOOP_COUNT && which != C_C1 && which != C_M2 && iters > 0,
                 "profile_loop_conv: conv %d is not a stand-alone launch of the recurrence", which);
     LoopProbe probe;
     probe.which = which;
+    probe.empty = empty;
     t_probe = &probe;
     int rc = enqueue_refine(desc, packed, pyramid, num_levels, radius, net, inp, nullptr, up_out, 0, nullptr, nullptr, workspace, B,
                             H, W, rate, iters, stream);
@@ -1053,6 +1060,20 @@ extern "C" int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const fl
     NND_REQUIRE(n > 0, "profile_loop_conv: needs at least 2 iterations");
     *ms_out = (float)(sum / n);
     return NND_OK;
+}
+
+extern "C" int nnd_profile_loop_conv(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
+                                     int radius, const float* net, const float* inp, float* up_out, float* workspace, int B, int H,
+                                     int W, int rate, int iters, int which, void* stream, float* ms_out) {
+    return profile_loop(desc, packed, pyramid, num_levels, radius, net, inp, up_out, workspace, B, H, W, rate, iters, which, stream, ms_out,
+                        false);
+}
+
+extern "C" int nnd_profile_loop_event_pair(const nnd_update_block_desc* desc, const float* packed, const float* pyramid, int num_levels,
+                                           int radius, const float* net, const float* inp, float* up_out, float* workspace, int B, int H,
+                                           int W, int rate, int iters, int which, void* stream, float* ms_out) {
+    return profile_loop(desc, packed, pyramid, num_levels, radius, net, inp, up_out, workspace, B, H, W, rate, iters, which, stream, ms_out,
+                        true);
 }
 
 // ------------------------------------------------------------------------------ MFMA peak probe

@@ -388,8 +388,10 @@ class UpdateBlockEngine:
         return ms.value, fl.value
 
 
-    def profile_loop_conv(self, which: int, pyr, num_levels: int, radius: int, net, inp, rate: int, iters: int) -> float:
-        """-> avg ms of conv `which` INSIDE the fused RAFT-Stereo loop (hipEvents on the launch stream in every iteration)."""
+    def profile_loop_conv(self, which: int, pyr, num_levels: int, radius: int, net, inp, rate: int, iters: int,
+                          event_pair_only: bool = False) -> float:
+        """-> avg ms of conv `which` INSIDE the fused RAFT-Stereo loop (hipEvents on the launch stream in every iteration).
+        event_pair_only: the calibration run — both events in front of the conv, nothing between them."""
         d = _dev(pyr, net, inp, self.packed)
         net, inp = net.contiguous(), inp.contiguous()
         B, _, H, W = net.shape
@@ -398,9 +400,9 @@ class UpdateBlockEngine:
         ws = self.workspace(B, H, W, d)
         ms = C.c_float()
         with torch.cuda.device(d):
-            check(lib.nnd_profile_loop_conv(C.byref(self.desc), _p(self.packed), _p(pyr), num_levels, radius, _p(net), _p(inp),
-                                            _p(up), _p(ws), B, H, W, rate, iters, which, _stream(d), C.byref(ms)),
-                  "profile_loop_conv")
+            fn = lib.nnd_profile_loop_event_pair if event_pair_only else lib.nnd_profile_loop_conv
+            check(fn(C.byref(self.desc), _p(self.packed), _p(pyr), num_levels, radius, _p(net), _p(inp),
+                     _p(up), _p(ws), B, H, W, rate, iters, which, _stream(d), C.byref(ms)), "profile_loop_conv")
         return ms.value
 
 
