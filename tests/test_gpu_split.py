@@ -376,3 +376,27 @@ def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monke
     for i, (x, y) in enumerate(zip(a, b)):
         assert torch.isfinite(x).all() and x.abs().max() > 0
         assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
+def test_loop_conv_probe_and_its_event_pair_calibration():
+    """bench.py's live measurement of a conv inside the fused loop (nnd_profile_loop_conv: events around the launch in every
+    iteration) and its calibration (nnd_profile_loop_event_pair: both events in front of the conv): both run the loop, the empty
+    pair is positive and shorter than the bracketed launch, and the loop's result is not disturbed by either."""
+    from nndepth_amd import weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.cost_volume import CorrBlock1D
+    torch.manual_seed(5)
+    B, H, W = 1, 24, 40
+    ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic="fp16x2")
+    weightgen.fill_module_(ub, "update_block.")
+    eng = ub.to(DEV).eval().sync_engine(DEV)
+    net, inp = torch.tanh(torch.randn(B, 128, H, W)).to(DEV), torch.relu(torch.randn(B, 64, H, W)).to(DEV)
+    pyr = CorrBlock1D(torch.randn(B, 256, H, W, device=DEV), torch.randn(B, 256, H, W, device=DEV), 4, 4)._pyr
+    names = eng.conv_names()
+    which = names.index("encoder.convc2")
+    before = [o.clone() for o in eng.refine(pyr, 4, 4, net, inp, 8, 6)]
+    raw = eng.profile_loop_conv(which, pyr, 4, 4, net, inp, 8, 6)
+    pair = eng.profile_loop_conv(which, pyr, 4, 4, net, inp, 8, 6, event_pair_only=True)
+    assert 0.0 < pair < raw < 5.0, (pair, raw)
+    after = [o.clone() for o in eng.refine(pyr, 4, 4, net, inp, 8, 6)]
+    assert all(torch.equal(x, y) for x, y in zip(before, after))
