@@ -25,6 +25,7 @@
 #include "layout.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -239,22 +240,45 @@ __global__ void __launch_bounds__(256) in_final_kernel(const double* __restrict_
 }
 
 // y = relu(x*alpha + beta) in place; with a shortcut: y = relu((sc*alpha_s + beta_s) + relu(x*alpha + beta)).
-// One thread per pixel of a (channel, sample) plane (tile-major incl. its padding: harmless, never read as data).
+// One thread per V consecutive pixels of a (channel, sample) plane (tile-major incl. its padding: harmless, never read as data);
+// V = 4: 16-byte loads and stores (planes are multiples of 32 floats; the launcher checks the base alignment), V = 1 otherwise.
+template <int V>
 __global__ void __launch_bounds__(256) in_apply_kernel(float* __restrict__ x, long bs, const float* __restrict__ stats,
                                                        const float* __restrict__ sc, long sbs, const float* __restrict__ sstats,
                                                        int C, long plane, int relu) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * V;
     if (i >= plane) return;
     const int c = blockIdx.y, n = blockIdx.z;
     const float a = stats[((long)n * C + c) * 2], b = stats[((long)n * C + c) * 2 + 1];
     float* p = x + (long)n * bs + (long)c * plane + i;
-    float v = fmaf(*p, a, b);
-    if (relu) v = fmaxf(v, 0.f);
-    if (sc) {
-        const float as = sstats[((long)n * C + c) * 2], bsft = sstats[((long)n * C + c) * 2 + 1];
-        v = fmaxf(fmaf(sc[(long)n * sbs + (long)c * plane + i], as, bsft) + v, 0.f);
+    float v[V], sv[V];
+    if (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1 % V] = t.y; v[2 % V] = t.z; v[3 % V] = t.w;
+    } else {
+        v[0] = *p;
     }
-    *p = v;
+    float as = 0.f, bsft = 0.f;
+    if (sc) {
+        as = sstats[((long)n * C + c) * 2];
+        bsft = sstats[((long)n * C + c) * 2 + 1];
+        const float* q = sc + (long)n * sbs + (long)c * plane + i;
+        if (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(q);
+            sv[0] = t.x; sv[1 % V] = t.y; sv[2 % V] = t.z; sv[3 % V] = t.w;
+        } else {
+            sv[0] = *q;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float r = fmaf(v[k], a, b);
+        if (relu) r = fmaxf(r, 0.f);
+        if (sc) r = fmaxf(fmaf(sv[k], as, bsft) + r, 0.f);
+        v[k] = r;
+    }
+    if (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+    else *p = v[0];
 }
 
 static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, float eps, float* stats, double* partial, hipStream_t s) {
@@ -268,8 +292,14 @@ static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, floa
 static int in_apply(float* x, int64_t bs, const float* stats, const float* sc, int64_t sbs, const float* sstats, int N, int C, int H,
                     int W, bool relu, hipStream_t s) {
     const long plane = tiled_plane(H, W);
-    hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)cdiv64(plane, 256), C, N), dim3(256), 0, s, x, (long)bs, stats, sc, (long)sbs,
-                       sstats, C, plane, relu ? 1 : 0);
+    const bool v4 = plane % 4 == 0 && bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                    (!sc || (sbs % 4 == 0 && reinterpret_cast<uintptr_t>(sc) % 16 == 0));
+    if (v4)
+        hipLaunchKernelGGL(in_apply_kernel<4>, dim3((unsigned)cdiv64(plane, 1024), C, N), dim3(256), 0, s, x, (long)bs, stats, sc, (long)sbs,
+                           sstats, C, plane, relu ? 1 : 0);
+    else
+        hipLaunchKernelGGL(in_apply_kernel<1>, dim3((unsigned)cdiv64(plane, 256), C, N), dim3(256), 0, s, x, (long)bs, stats, sc, (long)sbs,
+                           sstats, C, plane, relu ? 1 : 0);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }
