@@ -19,11 +19,11 @@
  *     every kernel of a call — the fused loops' too — is enqueued on the caller's `stream` and nowhere else
  *     (rounds 1-2 ran one branch of the loop on an internal side stream; measured equal, removed);
  *   - diagnostic environment switches (read ONCE when the library is loaded and again only by nnd_reload_switches(), never
- *     on the hot path; they select between kernels that the parity tests prove equivalent, never a non-HIP path; the
- *     packed-blob layout depends on NND_SPLIT_MASK, so do not reload between a pack and the forwards that use the blob): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
+ *     on the hot path; they select between kernels that the parity tests prove equivalent, never a non-HIP path; none of them
+ *     changes the layout of a packed blob — which convolutions of the update block take a split arithmetic is part of the
+ *     descriptor, nnd_update_block_desc.split_layers): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches),
  *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_MERGED_FB_LOOKUP (flow branch and lookup + convc1 as two launches instead of one launch of two kinds of workgroups), NND_DEBUG_LDS_POISON / NND_DEBUG_LDS_SLACK (diagnostics of the round-3 reproducibility study: pattern-fill every CU's LDS between the loop's launches / ask for more dynamic LDS), NND_SPLIT_NO_FAST (the generic conv_split kernel everywhere), NND_NO_FUSED_FLOW_BRANCH (convf1 and convf2 as two launches when
- *     arithmetic = 3), NND_SPLIT_MASK / NND_SPLIT_CFG (which convs take the
- *     split-bf16 kernel when arithmetic = 3 / force its workgroup shape), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
+ *     arithmetic = 3), NND_SPLIT_CFG (force the workgroup shape of the split kernel), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_AGCL_V1 (one-pixel-per-lane AGCL kernels), NND_AGCL_PB (pixels per workgroup of the channels-last offset kernel), NND_CONV_CFG / NND_CONV_P
  *     (force a tile configuration), NND_CONV_VERBOSE (print the chosen configuration), NND_DEBUG_SYNC
  *     (synchronise and name every launch of the update block on stderr), NND_NO_THIN3D (the regulariser's 8- / 16-channel
@@ -42,7 +42,16 @@
 extern "C" {
 #endif
 
-#define NND_VERSION 101 /* 0.1.1: nnd_cre_stereo_refine takes the size of its scratch; nnd_reload_switches */
+#define NND_VERSION 102 /* 0.1.2: descriptors carry struct_size and flags; per-layer fp16x2 activation scales + calibration */
+
+/* Descriptors start with `struct_size` = sizeof(the descriptor type) of the header the caller was compiled against; every entry
+ * point that takes one refuses another size (NND_ERR_INVALID), so a caller and a library of different versions cannot
+ * misread each other's fields.  `flags` is a bit set of NND_FLAG_*.                                                        */
+#define NND_FLAG_CALIBRATE 1 /* fp16x2 only: besides its normal work, the call records — for every layer it runs in that
+                                arithmetic — the largest |activation| the layer stages, in the layer's slot of the packed blob
+                                (`packed_dev` is WRITTEN by such a call; the extra kernels run on `stream` like everything
+                                else).  nnd_*_calibration_finish then fixes the layers' activation scales.  See "fp16x2
+                                activation range" below.                                                                    */
 
 typedef enum {
     NND_OK = 0,
@@ -158,7 +167,19 @@ int nnd_convex_upsample(const float* flow, const float* mask, float* out,
 /* -------------------------------------------------------------------------- update block
  * Replaces BasicUpdateBlock.forward (+BasicMotionEncoder, SepConvGRU/ConvGRU, FlowHead, mask head)
  *   nndepth/blocks/update_block.py:57-65,26-36,97-112 ; nndepth/blocks/gru.py:22-37,53-61   */
+/* fp16x2 activation range (arithmetic = 2; csrc/split_arith.h, csrc/calib.hip).  An fp32 activation x is carried as two fp16
+ * pieces of x * 2^xs with xs PER LAYER, stored in the packed blob and read by the kernels at run time.
+ *   - a freshly packed blob has xs = 2 for every layer: all 22 significand bits for 0.06 <= |x| < 16376, graceful below
+ *     (absolute error <= 2^-27), inf / NaN in the output above (never a silently wrong value);
+ *   - after a calibration — one or more forwards with NND_FLAG_CALIBRATE on representative inputs, then
+ *     nnd_*_calibration_finish — each layer has xs = 11 - ceil(log2(M)), M = the largest |activation| that layer staged
+ *     during those forwards: all 22 bits for M * 2^-13 <= |x| <= M, absolute error <= M * 2^-36 below, valid (finite) up to
+ *     |x| < 32 * M, inf / NaN in the output beyond;
+ *   - nnd_update_block_scale_slots gives the float offsets of the layers' slots in the blob: slot[1] = 2^xs, so the valid range
+ *     of layer i is |x| < 65504 / slot[1] (the Python engines expose it as `activation_ranges()`).
+ * The model classes of nndepth_amd calibrate on their first forward (one extra forward, once).                              */
 typedef struct {
+    int32_t struct_size;   /* sizeof(nnd_update_block_desc) */
     int32_t hidden_dim;    /* 128 */
     int32_t context_dim;   /* 64 (YAML) or 128 (class default) */
     int32_t cor_planes;    /* num_levels*(2r+1) = 36; 576 for IGEV */
@@ -174,9 +195,13 @@ typedef struct {
                               pieces (22 significand bits), the 3 products x0*w0, x0*w1, x1*w0 on v_mfma_f32_32x32x16_f16 with
                               fp32 accumulation — half the matrix work of 3; both operands are range-scaled by exact powers of two
                               (activations x4 while staged, weights per layer at pack time) that the kernel undoes after the K
-                              loop, so the low pieces stay out of fp16's subnormals; valid for activations |x| < 16376 (beyond:
-                              inf / NaN in the output, never a silently wrong value); csrc/split_arith.h.
+                              loop, so the low pieces stay out of fp16's subnormals; the activation scale is per layer and
+                              calibrated from data, see "fp16x2 activation range" above; csrc/split_arith.h.
                               The packed blob is specific to the value. */
+    int32_t split_layers;  /* 0: every convolution the split kernels are built for takes `arithmetic`; else bit i = convolution i
+                              (nnd_conv_name) may take it, the others stay exact fp32 (diagnostic: bisecting a difference).  Part
+                              of the blob layout, like `arithmetic`: use the same value to pack and to run. */
+    int32_t flags;         /* NND_FLAG_* */
 } nnd_update_block_desc;
 
 /* Number of weight/bias tensors expected by nnd_update_block_pack, in the order of the
@@ -193,6 +218,17 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
                           float* packed_host);
 /* workspace (floats) needed by nnd_update_block_forward / nnd_raft_stereo_refine          */
 int64_t nnd_update_block_workspace_floats(const nnd_update_block_desc* desc, int B, int H, int W);
+/* fp16x2 calibration (see "fp16x2 activation range"): after one or more calls of nnd_update_block_forward / nnd_*_refine with
+ * NND_FLAG_CALIBRATE on this blob, turns the recorded maxima into the layers' activation scales (one tiny kernel on `stream`, no
+ * synchronisation) and clears the records.  status_dev: optional device int32 that receives |= 1 if a recorded maximum was
+ * inf / NaN (the calibration forward itself overflowed at the old scale: that layer's scale was lowered by 2^12 — calibrate
+ * again), |= 2 if some fp16x2 layer of the blob staged nothing (not on the path of those calls: its scale is unchanged).
+ * No-op for the other arithmetics.
+ * nnd_update_block_scale_slots: float offsets inside the blob of the 4-float slots {2^-(s+xs), 2^xs, record, 2^-s} of the
+ * convolutions 0 .. n-1 in nnd_conv_name order (-1 where a convolution is not fp16x2); returns how many convolutions the
+ * descriptor has (call with offsets = NULL to size the array).                                                            */
+int nnd_update_block_calibration_finish(const nnd_update_block_desc* desc, float* packed_dev, int32_t* status_dev, void* stream);
+int nnd_update_block_scale_slots(const nnd_update_block_desc* desc, int64_t* offsets, int n);
 
 /* (net, inp, corr, flow) -> (net_out, mask_out, delta_out); same shapes as the reference:
  * net (B,hidden,H,W) inp (B,context,H,W) corr (B,cor_planes,H,W) flow (B,fc,H,W)
@@ -222,6 +258,10 @@ int nnd_conv2d_pack_ex(const float* w_host, const float* b_host, int Cout, int C
                        float* packed_host);
 int nnd_conv2d_forward_ex(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W,
                           int Cout, int KH, int KW, int relu, int arithmetic, void* stream);
+/* fp16x2 calibration of such a single layer (arithmetic == 2; no-op otherwise): sets the blob's activation scale from the
+ * largest |x| of this input (see "fp16x2 activation range").  status_dev as nnd_update_block_calibration_finish.          */
+int nnd_conv2d_calibrate_ex(float* packed_dev, const float* x, int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                            int arithmetic, int32_t* status_dev, void* stream);
 
 /* conv + CREStereo's search-offset activation in the epilogue: y = range * (sigmoid(conv(x)) - 0.5) * 2
  *   nndepth/models/cre_stereo/model.py:158-159,171-172 (conv_offset_16 / conv_offset_8); blob of nnd_conv2d_pack.      */
@@ -267,9 +307,12 @@ int nnd_conv_forward(const nnd_conv_desc* desc, const float* packed_dev, const f
  * nnd_encoder_forward: frames (N,3,H,W) -> fmap (N,output_dim,H/8,W/8); cnet_out (n_cnet,cnet_dim,H/8,W/8) or NULL.
  * workspace: nnd_encoder_workspace_floats(desc, N, H, W) floats, caller-owned.                                     */
 typedef struct nnd_encoder_desc {
-    int output_dim, norm, cnet_dim;
-    int arithmetic; /* 0 = exact fp32 MFMA; 3 / 2 = the stride-1 3x3 convolutions (and cnet_proj) on the 16-bit MFMA with 3 bf16 /
-                       2 fp16 split operands (see nnd_update_block_desc.arithmetic); stem, stride-2 and 1x1 layers stay fp32 */
+    int32_t struct_size; /* sizeof(nnd_encoder_desc) */
+    int32_t output_dim, norm, cnet_dim;
+    int32_t arithmetic; /* 0 = exact fp32 MFMA; 3 / 2 = the 3x3 convolutions at stride 1 and 2, the stride-2 1x1 shortcuts and
+                           cnet_proj on the 16-bit MFMA with 3 bf16 / 2 fp16 split operands (see nnd_update_block_desc.arithmetic);
+                           the stem, the stride-1 1x1 shortcuts and the 1x1 output conv stay exact fp32 */
+    int32_t flags;      /* NND_FLAG_* */
 } nnd_encoder_desc;
 int nnd_encoder_num_tensors(const nnd_encoder_desc* desc);
 int64_t nnd_encoder_packed_floats(const nnd_encoder_desc* desc);
@@ -277,6 +320,8 @@ int64_t nnd_encoder_workspace_floats(const nnd_encoder_desc* desc, int N, int H,
 int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* tensors_host, float bn_eps, float* packed_host);
 int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed_dev, const float* frames, float* fmap,
                         float* cnet_out, int n_cnet, float* workspace, int N, int H, int W, void* stream);
+/* fp16x2 calibration of the encoder's layers after forwards with NND_FLAG_CALIBRATE (as nnd_update_block_calibration_finish) */
+int nnd_encoder_calibration_finish(const nnd_encoder_desc* desc, float* packed_dev, int32_t* status_dev, void* stream);
 
 /* ------------------------------------------------------------- pre- / post-processing on the device
  * nnd_resize_normalize : preprocess_frame  nndepth/models/raft_stereo/scripts/inference.py:55-60
@@ -319,15 +364,19 @@ int nnd_loftr_layer_forward(int d_model, int nhead, const float* packed_dev, con
  * depth-marching 16-bit-MFMA kernel (csrc/slab3d.hip).  Cin1 = 0: single input.
  * nnd_conv3d_pack (HOST): w (Cout, Cin0+Cin1, 3, 3, 3), bias / bn_* may be NULL.  leaky_slope 1 = no activation.          */
 typedef struct nnd_conv3d_desc {
-    int Cout, Cin0, Cin1, stride;
-    int arithmetic; /* 0 = exact fp32 MFMA; 3 / 2 = 16-bit MFMA with 3 bf16 / 2 fp16 split operands for the stride-1 layers
-                       (see nnd_update_block_desc.arithmetic) */
+    int32_t struct_size; /* sizeof(nnd_conv3d_desc) */
+    int32_t Cout, Cin0, Cin1, stride;
+    int32_t arithmetic; /* 0 = exact fp32 MFMA; 3 / 2 = 16-bit MFMA with 3 bf16 / 2 fp16 split operands
+                           (see nnd_update_block_desc.arithmetic) */
+    int32_t flags;      /* NND_FLAG_* */
 } nnd_conv3d_desc;
 int64_t nnd_conv3d_packed_floats(const nnd_conv3d_desc* desc);
 int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w_host, const float* bias_host, const float* bn_gamma,
                     const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, float* packed_host);
 int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed_dev, const float* x0, const float* x1, float* y,
                        int N, int D, int H, int W, float leaky_slope, void* stream);
+/* fp16x2 calibration of the layer after forwards with NND_FLAG_CALIBRATE (as nnd_update_block_calibration_finish) */
+int nnd_conv3d_calibration_finish(const nnd_conv3d_desc* desc, float* packed_dev, int32_t* status_dev, void* stream);
 int nnd_volume_to_depth_major(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
 int nnd_depth_major_to_volume(const float* x, float* y, int N, int C, int D, int H, int W, void* stream);
 /* the same for a volume stored (N, C, H, W, D), candidate axis contiguous — level 0 of the IGEV pyramids, rows

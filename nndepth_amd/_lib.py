@@ -14,22 +14,35 @@ class NndError(RuntimeError):
     pass
 
 
-class UpdateBlockDesc(C.Structure):
-    _fields_ = [("hidden_dim", C.c_int32), ("context_dim", C.c_int32), ("cor_planes", C.c_int32),
+NND_FLAG_CALIBRATE = 1
+
+
+class _SizedDesc(C.Structure):
+    """Descriptors start with struct_size = sizeof(the struct) (include/nndepth_amd.h): filled in here, so the
+    constructors keep taking the payload fields only."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(C.sizeof(type(self)), *args, **kwargs)
+
+
+class UpdateBlockDesc(_SizedDesc):
+    _fields_ = [("struct_size", C.c_int32), ("hidden_dim", C.c_int32), ("context_dim", C.c_int32), ("cor_planes", C.c_int32),
                 ("flow_channels", C.c_int32), ("mask_channels", C.c_int32), ("gru_kind", C.c_int32),
-                ("arithmetic", C.c_int32)]
+                ("arithmetic", C.c_int32), ("split_layers", C.c_int32), ("flags", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
     _fields_ = [("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32)]
 
 
-class Conv3dDesc(C.Structure):
-    _fields_ = [("Cout", C.c_int32), ("Cin0", C.c_int32), ("Cin1", C.c_int32), ("stride", C.c_int32), ("arithmetic", C.c_int32)]
+class Conv3dDesc(_SizedDesc):
+    _fields_ = [("struct_size", C.c_int32), ("Cout", C.c_int32), ("Cin0", C.c_int32), ("Cin1", C.c_int32), ("stride", C.c_int32),
+                ("arithmetic", C.c_int32), ("flags", C.c_int32)]
 
 
-class EncoderDesc(C.Structure):
-    _fields_ = [("output_dim", C.c_int32), ("norm", C.c_int32), ("cnet_dim", C.c_int32), ("arithmetic", C.c_int32)]
+class EncoderDesc(_SizedDesc):
+    _fields_ = [("struct_size", C.c_int32), ("output_dim", C.c_int32), ("norm", C.c_int32), ("cnet_dim", C.c_int32),
+                ("arithmetic", C.c_int32), ("flags", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/nndepth_amd.h one to one
@@ -58,6 +71,11 @@ SIGNATURES = {
     "nnd_update_block_pack": (_I, [C.POINTER(UpdateBlockDesc), C.POINTER(_P), _P]),
     "nnd_update_block_workspace_floats": (C.c_int64, [C.POINTER(UpdateBlockDesc), _I, _I, _I]),
     "nnd_update_block_forward": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "nnd_update_block_calibration_finish": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P]),
+    "nnd_update_block_scale_slots": (_I, [C.POINTER(UpdateBlockDesc), C.POINTER(C.c_int64), _I]),
+    "nnd_conv2d_calibrate_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "nnd_encoder_calibration_finish": (_I, [C.POINTER(EncoderDesc), _P, _P, _P]),
+    "nnd_conv3d_calibration_finish": (_I, [C.POINTER(Conv3dDesc), _P, _P, _P]),
     "nnd_conv2d_packed_floats": (C.c_int64, [_I, _I, _I, _I]),
     "nnd_conv2d_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "nnd_conv2d_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -28,7 +28,7 @@ from ._lib import NndError
 from .blocks import BasicUpdateBlock
 from .cost_volume import AGCL
 from .encoder import BasicEncoder
-from .raft_stereo import hip_encoder_blocker, load_weights, require_eval
+from .raft_stereo import AutoCalibrate, hip_encoder_blocker, load_weights, require_eval
 from .upsample import convex_upsample
 
 
@@ -129,7 +129,7 @@ def _position_encoding_sine_host(d_model: int, h: int, w: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ the model
-class CREStereoBase(nn.Module):
+class CREStereoBase(AutoCalibrate, nn.Module):
     def __init__(self, fnet_cls: str = "basic_encoder", update_cls: str = "basic_update_block", iters: int = 12,
                  max_disp: int = 192, num_fnet_channels: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  search_num: int = 9, mixed_precision: bool = False, test_mode: bool = False, tracing: bool = False,
@@ -217,7 +217,7 @@ class CREStereoBase(nn.Module):
                 upsample: bool = True, test_mode: bool = False, **kwargs):
         require_eval(self)
         with torch.no_grad():
-            return self._forward(frame1, frame2, flow_init)
+            return self._forward_calibrated(frame1, frame2, flow_init)
 
     def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor, flow_init: Optional[torch.Tensor] = None):
         frame1, frame2 = frame1.contiguous(), frame2.contiguous()

@@ -42,7 +42,6 @@ void set_error(const char* fmt, ...);
 struct Switches {
     bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, no_conv1x1_stream,
         conv_verbose, debug_sync;
-    unsigned split_mask;              // NND_SPLIT_MASK: bit = ConvId of the update-block convs that may take the split kernel
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
     bool no_merged_fb_lookup;         // NND_NO_MERGED_FB_LOOKUP: flow branch and lookup + convc1 as two launches
@@ -68,6 +67,31 @@ static inline int raise_lds_limit(const void* kern, std::atomic<unsigned>& done)
     }
     return NND_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// fp16x2 activation-range calibration (calib.hip, split_arith.h): an entry point called with NND_FLAG_CALIBRATE opens a
+// CalibScope on the calling thread; while it is open every launcher of a kernel that stages fp16x2 activations first measures
+// the largest |activation| of what the launch will stage into the layer's slot of the packed blob (calib_amax_*), and
+// nnd_*_calibration_finish turns the slots into the layers' activation scales (calib_finish).  Thread-local: a forward running
+// on another host thread is not affected.
+// ---------------------------------------------------------------------------------------
+bool calibrating();
+struct CalibScope {
+    explicit CalibScope(bool on);
+    ~CalibScope();
+    CalibScope(const CalibScope&) = delete;
+    CalibScope& operator=(const CalibScope&) = delete;
+    bool on;
+};
+struct Act;
+struct Lay;
+// `tail`: the layer's 4-float slot (SPLIT_TAIL_*) inside the packed blob on the device (written: the AMAX element)
+int calib_amax_act(const Act& a, const Lay& lay, int B, int H, int W, const float* tail, hipStream_t s);
+int calib_amax_flat(const float* x, int64_t n, const float* tail, hipStream_t s);
+// turns the accumulated maxima of `n` layers (float offsets of their tails inside `blob`) into activation scales; *status_dev
+// (optional, device int32) |= 1 if a maximum was inf / NaN (the calibration forward itself overflowed: that layer's scale is lowered
+// by 2^12, calibrate again), |= 2 if a layer staged nothing (scale unchanged)
+int calib_finish(float* blob, const int64_t* tail_offs, int n, int32_t* status_dev, hipStream_t s);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -104,6 +128,7 @@ struct ConvLayer {
     }
     int64_t b_floats() const { return (int64_t)ncb * 32 + (arith == 2 ? 4 : 0); }  // fp16x2: + the output scale (split_arith.h)
     double flops(int B, int H, int W) const { return 2.0 * B * H * W * (double)Cout * Cin * KH * KW; }
+    int64_t tail_off() const { return b_off + (int64_t)ncb * 32; }  // fp16x2: float offset of the SPLIT_TAIL_* slot (split_arith.h)
 };
 
 // A source / destination activation: channel-slice of an NCHW tensor (channel stride = H*W).

@@ -27,6 +27,9 @@ static int group_of(const nnd_conv3d_desc* d) {
 
 static int conv3d_layer(const nnd_conv3d_desc* d, int J, ConvLayer* L, int64_t* total) {
     NND_REQUIRE(d, "conv3d: null descriptor");
+    NND_REQUIRE(d->struct_size == (int32_t)sizeof(nnd_conv3d_desc), "conv3d: descriptor of %d bytes, this library expects %d (struct_size)",
+                d->struct_size, (int)sizeof(nnd_conv3d_desc));
+    NND_REQUIRE((d->flags & ~NND_FLAG_CALIBRATE) == 0, "conv3d: unknown flags 0x%x", d->flags);
     NND_REQUIRE(d->Cout > 0 && d->Cin0 > 0 && d->Cin1 >= 0, "conv3d: bad channel counts");
     NND_REQUIRE(d->stride == 1 || d->stride == 2, "conv3d: stride %d not supported (1, 2)", d->stride);
     NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3 || d->arithmetic == 2, "conv3d: arithmetic must be 0 (fp32 MFMA), 3 (bf16x3) or 2 (fp16x2)");
@@ -341,6 +344,26 @@ int nnd_conv3d_pack(const nnd_conv3d_desc* desc, const float* w, const float* bi
 
 // x0 (N, D+2, Cin0, H, W), x1 (N, D+2, Cin1, H, W) or NULL, y (N, Do+2, Cout, Ho, Wo) — all depth-major with zero end slices
 // (y's end slices are written by this call); Do = ceil(D/stride) etc.  leaky_slope: LeakyReLU negative slope (1 = none).
+// every formulation of the layer that is packed in fp16x2 has its own slot; the one the forwards did not take reports "staged nothing"
+int nnd_conv3d_calibration_finish(const nnd_conv3d_desc* desc, float* packed_dev, int32_t* status_dev, void* stream) {
+    ConvLayer L1, LJ;
+    int64_t t1, tj = 0;
+    int rc = conv3d_layer(desc, 1, &L1, &t1);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev, "conv3d_calibration_finish: null blob");
+    const int J = group_of(desc);
+    if (J > 1 && (rc = conv3d_layer(desc, J, &LJ, &tj)) != NND_OK) return rc;
+    int64_t offs[3];
+    int n = 0;
+    if (L1.arith == 2) offs[n++] = L1.tail_off();
+    if (J > 1 && LJ.arith == 2) offs[n++] = t1 + LJ.tail_off();
+    if (slab3d_supported(desc->Cout, desc->Cin0, desc->Cin1, desc->stride, desc->arithmetic)) {
+        const int64_t tt = thin3d_supported(desc->Cout, desc->stride) ? thin3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1) : 0;
+        offs[n++] = t1 + tj + tt + slab3d_packed_floats(desc->Cout, desc->Cin0 + desc->Cin1, desc->stride) - 4;
+    }
+    return calib_finish(packed_dev, offs, n, status_dev, (hipStream_t)stream);
+}
+
 int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const float* x0, const float* x1, float* y, int N, int D,
                        int H, int W, float leaky_slope, void* stream) {
     ConvLayer L;
@@ -349,6 +372,7 @@ int nnd_conv3d_forward(const nnd_conv3d_desc* desc, const float* packed, const f
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && x0 && y && (desc->Cin1 == 0 || x1), "conv3d_forward: null pointer");
     NND_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_forward: bad shape");
+    CalibScope calib((desc->flags & NND_FLAG_CALIBRATE) && desc->arithmetic == 2);
     hipStream_t s = (hipStream_t)stream;
     if (use_slab(desc) || use_thin(desc)) {
         const int st0 = desc->stride;

@@ -221,6 +221,11 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     NND_REQUIRE(epi != EPI_AFFINE || a.cscale, "conv_split: EPI_AFFINE needs a packed scale vector");
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks; a.npos = cfg.ntiles;
     a.scale = io.scale;
+    if (calibrating() && L.arith == 2) {  // record the largest |activation| this launch stages (calib.hip)
+        const float* tail = blob + L.tail_off();
+        if (int rc = calib_amax_act(io.src0, a.ls, B, Hin, Win, tail, stream)) return rc;
+        if (int rc = calib_amax_act(io.src1, a.ls, B, Hin, Win, tail, stream)) return rc;
+    }
     dim3 grid(cdiv(cfg.ntiles, cfg.P), cfg.ny, B), block(64 * cfg.wco * cfg.ks);
     const bool verbose = switches().conv_verbose;
     if (verbose)
@@ -237,8 +242,10 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
 
 // Host packer: same (cout, cin_src, KH, KW) inputs as pack_conv; blob order [cb][chunk][tap][piece][lane][8] 16-bit values with
 // lane = h*32 + (co % 32) holding channels chunk*16 + 8h + 0..7 (the A operand of v_mfma_f32_32x32x16_{bf16,f16}).
-// fp16x2 (arith 2): the pieces are those of w * 2^s, s per layer such that max|w| * 2^s lies in [2^13, 2^14), and the float behind
-// the bias vector (bias[ncb*32]) is oscale = 2^-(s + SPLIT_F16_XSHIFT), which the kernels multiply their accumulators by.
+// fp16x2 (arith 2): the pieces are those of w * 2^s, s per layer such that max|w| * 2^s lies in [2^13, 2^14), and the 4 floats
+// behind the bias vector (bias[ncb*32 ...], split_arith.h: SPLIT_TAIL_*) are oscale = 2^-(s + xs), which the kernels multiply their
+// accumulators by, the activation scale 2^xs (xs = SPLIT_F16_XSHIFT until the layer is calibrated), the calibration accumulator
+// and 2^-s.
 void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, const float* const* bvec, const int* cout, float* blob,
                      const int* ci_map, int cin_src) {
     if (!ci_map) cin_src = L.Cin;
@@ -261,7 +268,11 @@ void pack_conv_split(const ConvLayer& L, int nparts, const float* const* w, cons
         if (wmax > 0.f) std::frexp(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)  ->  wmax * 2^(14 - e) in [2^13, 2^14)
         const int s = wmax > 0.f ? 14 - e : 0;
         wscale = std::ldexp(1.f, s);
-        bp[L.ncb * 32] = std::ldexp(1.f, -(s + SPLIT_F16_XSHIFT));
+        float* tail = bp + L.ncb * 32;  // split_arith.h: SPLIT_TAIL_*
+        tail[SPLIT_TAIL_OSCALE] = std::ldexp(1.f, -(s + SPLIT_F16_XSHIFT));
+        tail[SPLIT_TAIL_XSCALE] = std::ldexp(1.f, SPLIT_F16_XSHIFT);  // until the layer is calibrated (calib.hip)
+        tail[SPLIT_TAIL_AMAX] = 0.f;
+        tail[SPLIT_TAIL_WSINV] = std::ldexp(1.f, -s);
     }
     int co0 = 0;
     for (int part = 0; part < nparts; ++part) {

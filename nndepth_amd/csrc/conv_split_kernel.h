@@ -120,8 +120,12 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     const long SP = a.ls.plane;
     const int SCH = ks * 16;  // channels per super-chunk
     // fp16x2: the power-of-two scale that undoes the range scaling of both operands (packed behind the bias), requested now
-    float oscale = 1.f;
-    if constexpr (NS == 2) oscale = a.bias[((a.Cout + 31) >> 5) << 5];
+    float oscale = 1.f, xscale = 1.f;  // xscale: the layer's activation scale (calibrated per layer, split_arith.h)
+    if constexpr (NS == 2) {
+        const float* tail = a.bias + (((a.Cout + 31) >> 5) << 5);
+        oscale = tail[SPLIT_TAIL_OSCALE];
+        xscale = tail[SPLIT_TAIL_XSCALE];
+    }
 
     int ty0[P], tx0[P];
 #pragma unroll
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (inimg[i] && (FAST || cho[i] + j < climit)) ? stage[i][j] : 0.f;
         uint4 pieces[NS];
-        split_pieces<NS>(v, pieces);
+        split_pieces<NS>(v, pieces, xscale);
         if (own[i]) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4*>(buf + loff[i] + s * 32) = pieces[s];

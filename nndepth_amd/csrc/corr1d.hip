@@ -915,8 +915,11 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_split_kernel(con
     const long HW = (long)H * W;
     float br[16];
     load_c1_bias(bias, wave, h2, br);
-    float oscale = 1.f;
-    if constexpr (NS == 2) oscale = bias[256];  // behind the 8 x 32 bias values of the packed layer (split_arith.h)
+    float oscale = 1.f, xscale = 1.f;
+    if constexpr (NS == 2) {  // behind the 8 x 32 bias values of the packed layer (split_arith.h)
+        oscale = bias[256 + SPLIT_TAIL_OSCALE];
+        xscale = bias[256 + SPLIT_TAIL_XSCALE];
+    }
     const int vg = tid & 15;
     long pixo[2];
     float cval[2];
@@ -962,7 +965,7 @@ __global__ void __launch_bounds__(512, 2) igev_lookup_convc1_il_split_kernel(con
                 x = x * wm1;
                 const float cf = ceilf(x) - x;
                 float res = pin[i] ? cf * v0[i][k] + (1.0f - cf) * v1[i][k] : 0.f;  // the sample, in the reference's op order
-                if constexpr (NS == 2) res = res * split_x_scale(2);
+                if constexpr (NS == 2) res = res * xscale;
                 const int ch = vg * IL_NTAP + k;                              // channel inside the level
                 unsigned short* dst = reinterpret_cast<unsigned short*>(buf + (((ch >> 4) * NS * 2 + ((ch >> 3) & 1)) * 64 + pcol[i]) * 16) + (ch & 7);
 #pragma unroll

@@ -321,6 +321,9 @@ struct EncPlan {
 
 static int make_enc_plan(const nnd_encoder_desc* d, EncPlan* p) {
     NND_REQUIRE(d, "encoder: null descriptor");
+    NND_REQUIRE(d->struct_size == (int32_t)sizeof(nnd_encoder_desc), "encoder: descriptor of %d bytes, this library expects %d (struct_size)",
+                d->struct_size, (int)sizeof(nnd_encoder_desc));
+    NND_REQUIRE((d->flags & ~NND_FLAG_CALIBRATE) == 0, "encoder: unknown flags 0x%x", d->flags);
     NND_REQUIRE(d->output_dim > 0 && d->cnet_dim >= 0, "encoder: bad output_dim / cnet_dim");
     NND_REQUIRE(d->norm >= 0 && d->norm <= 2, "encoder: norm must be 0 (none), 1 (batch, eval) or 2 (instance); group norm is not built");
     NND_REQUIRE(d->arithmetic == 0 || d->arithmetic == 3 || d->arithmetic == 2, "encoder: arithmetic must be 0 (fp32 MFMA), 3 (bf16x3) or 2 (fp16x2)");
@@ -472,6 +475,22 @@ int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* t, float 
 
 // frames (N,3,H,W) NCHW -> fmap (N,output_dim,H8,W8) NCHW, H8 = ceil(ceil(ceil(H/2)/2)/2); cnet_out (optional, needs
 // cnet_dim > 0): ReLU(cnet_proj(fmap[:n_cnet])) (n_cnet,cnet_dim,H8,W8).
+int nnd_encoder_calibration_finish(const nnd_encoder_desc* desc, float* packed_dev, int32_t* status_dev, void* stream) {
+    EncPlan p;
+    int rc = make_enc_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev, "encoder_calibration_finish: null blob");
+    int64_t offs[3 * ENC_BLOCKS + 1];
+    int n = 0;
+    for (int i = 0; i < ENC_BLOCKS; ++i) {
+        if (p.c1[i].arith == 2) offs[n++] = p.base1[i] + p.c1[i].tail_off();
+        if (p.c2[i].arith == 2) offs[n++] = p.base2[i] + p.c2[i].tail_off();
+        if (p.ds[i].arith == 2 && (p.strides[i] != 1 || p.inpl[i] != p.planes[i])) offs[n++] = p.based[i] + p.ds[i].tail_off();
+    }
+    if (desc->cnet_dim > 0 && p.cnet.arith == 2) offs[n++] = p.base_cnet + p.cnet.tail_off();
+    return calib_finish(packed_dev, offs, n, status_dev, (hipStream_t)stream);
+}
+
 int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const float* frames, float* fmap, float* cnet_out,
                         int n_cnet, float* workspace, int N, int H, int W, void* stream) {
     EncPlan p;
@@ -479,6 +498,7 @@ int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && frames && fmap && workspace && N > 0 && H > 0 && W > 0, "encoder_forward: bad argument");
     NND_REQUIRE(!cnet_out || (desc->cnet_dim > 0 && n_cnet > 0 && n_cnet <= N), "encoder_forward: cnet_out needs cnet_dim > 0 and 0 < n_cnet <= N");
+    CalibScope calib((desc->flags & NND_FLAG_CALIBRATE) && desc->arithmetic == 2);
     hipStream_t s = (hipStream_t)stream;
     const int64_t bufsz = enc_buf_floats(N, H, W);
     float* buf[4] = {workspace, workspace + bufsz, workspace + 2 * bufsz, workspace + 3 * bufsz};

@@ -26,8 +26,6 @@ static void load_switches() {
     s.no_conv1x1_stream = on("NND_NO_CONV1X1_STREAM");
     s.conv_verbose = on("NND_CONV_VERBOSE");
     s.debug_sync = on("NND_DEBUG_SYNC");
-    s.split_mask = ~0u;
-    if (const char* e = getenv("NND_SPLIT_MASK")) s.split_mask = (unsigned)strtoul(e, nullptr, 0);
     s.split_ny = s.split_ks = s.split_p = -1;
     if (const char* e = getenv("NND_SPLIT_CFG")) sscanf(e, "%d,%d,%d", &s.split_ny, &s.split_ks, &s.split_p);
     s.split_no_fast = on("NND_SPLIT_NO_FAST");

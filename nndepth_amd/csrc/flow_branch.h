@@ -58,8 +58,12 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
     // fragments are requested NOW: they depend on nothing and arrive while phases 0 and 1 run.
     const int cbi = wave & 1, kj = wave >> 1;
     const uint4* wq = reinterpret_cast<const uint4*>(a.c.wpk) + (size_t)cbi * FB_NCH * (9 * NS * 64) + lane;
-    float oscale = 1.f;
-    if constexpr (NS == 2) oscale = a.c.bias[((a.c.Cout + 31) >> 5) << 5];  // undoes the fp16 range scaling (split_arith.h)
+    float oscale = 1.f, xscale = 1.f;
+    if constexpr (NS == 2) {  // undoes the fp16 range scaling / the layer's activation scale (split_arith.h)
+        const float* tail = a.c.bias + (((a.c.Cout + 31) >> 5) << 5);
+        oscale = tail[SPLIT_TAIL_OSCALE];
+        xscale = tail[SPLIT_TAIL_XSCALE];
+    }
     constexpr int NSTEP = (FB_NCH / 4) * 9;  // (chunk, tap) steps of a K slice
     constexpr int FB_AD = 5, NA = FB_AD + 1;
     uint4 ab[NA][NS];
@@ -126,7 +130,7 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
 #pragma unroll
                 for (int j = 0; j < 8; ++j) val[j] = in ? fmaxf(acc[p][j] + b7l[g * 16 + 8 * h + j], 0.f) : 0.f;
                 uint4 pieces[NS];
-                split_pieces<NS>(val, pieces);
+                split_pieces<NS>(val, pieces, xscale);
 #pragma unroll
                 for (int sp = 0; sp < NS; ++sp)
                     *reinterpret_cast<uint4*>(patch + g * SUBB + pr * ROWB + pc * PS + sp * 32 + h * 16) = pieces[sp];

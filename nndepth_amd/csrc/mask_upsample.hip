@@ -87,8 +87,11 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     const int H = a.H, W = a.W;
     const long HW = (long)H * W;
     const long XP = a.lay.plane;
-    float oscale = 1.f;  // fp16x2: undoes the power-of-two range scaling of both operands (packed behind the bias)
-    if constexpr (NS == 2) oscale = a.bias[Cfg::NCB * 32];
+    float oscale = 1.f, xscale = 1.f;  // fp16x2: undoes the power-of-two range scaling of both operands / the layer's activation scale (packed behind the bias, split_arith.h)
+    if constexpr (NS == 2) {
+        oscale = a.bias[Cfg::NCB * 32 + SPLIT_TAIL_OSCALE];
+        xscale = a.bias[Cfg::NCB * 32 + SPLIT_TAIL_XSCALE];
+    }
 
     // ---- stage the x tile (all CIN channels) and the flow patch
     {
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
                     const int chunk = qd >> 2, sub = qd & 3;
                     constexpr int NP = NS == 0 ? 3 : NS;
                     uint2 pv[NP];
-                    split_pieces_n<NP, 4, uint2>(res, pv);  // round-to-nearest of the running residual (split_arith.h)
+                    split_pieces_n<NP, 4, uint2>(res, pv, xscale);  // round-to-nearest of the running residual (split_arith.h)
 #pragma unroll
                     for (int sp = 0; sp < NP; ++sp)
                         *reinterpret_cast<uint2*>(xsb + ((((chunk * NP + sp) * 2 + (sub >> 1)) * 32 + px) * 16 + (sub & 1) * 8)) = pv[sp];
@@ -370,6 +373,10 @@ int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, 
         return launch_mu<4, 128, 3>(a, B, stream);
     }
     if (L.arith == 2) {  // range-scaled fp16 pieces
+        if (calibrating()) {  // record the largest |x| this launch stages (calib.hip)
+            const Act xa{const_cast<float*>(x), xbs, L.Cin};
+            if (int rc = calib_amax_act(xa, make_lay(H, W, tiled, x_c4), B, H, W, blob + L.tail_off(), stream)) return rc;
+        }
         if (rate == 8 && L.Cin == 256) return launch_mu<8, 256, 2>(a, B, stream);
         if (rate == 8 && L.Cin == 128) return launch_mu<8, 128, 2>(a, B, stream);
         if (rate == 4 && L.Cin == 256) return launch_mu<4, 256, 2>(a, B, stream);

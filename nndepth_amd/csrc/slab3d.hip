@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256, (Slab3dShape<CIN, COUT, STR>::MINW)) slab
                         // bytes would put the whole dwordx2 out of the descriptor's range and lose column 0 with it)
     bool uok[NR];       // there is a unit
     const unsigned plane = 4u * (unsigned)HW, plane_o = 4u * (unsigned)HWo;
+    const float xscale = a.scale[2 * COUT + SPLIT_TAIL_XSCALE];  // the layer's activation scale (split_arith.h)
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         // unit order: pairs along the slab rows of one channel plane fastest (a wave-wide load then touches ~10 cache lines; with
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256, (Slab3dShape<CIN, COUT, STR>::MINW)) slab
         const int c = src * CS + qg * 4;  // channel of the concat
         ulds[r] = (c >> 3) * NPOS * 16 + S::pos(py, px) + ((c >> 2) & 1) * 8;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) usc[r][e] = oky && gx + e >= 0 && gx + e < a.W ? split_x_scale(2) : 0.f;
+        for (int e = 0; e < 2; ++e) usc[r][e] = oky && gx + e >= 0 && gx + e < a.W ? xscale : 0.f;
     }
     constexpr int ESTEP = S::pos(0, 1) - S::pos(0, 0);  // from the pair's first position to its second
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0) + (long)n * (a.D + 2) * CS * HW, 0,
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(256, (Slab3dShape<CIN, COUT, STR>::MINW)) slab
     // per-lane epilogue constants: rows q*4 + i of M tile mt -> (output slice od, channel co)
     float sc[MT][4], sh[MT][4];
     unsigned orow[MT][4];
-    const float oscale = a.scale[2 * COUT];
+    const float oscale = a.scale[2 * COUT + SPLIT_TAIL_OSCALE];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -462,7 +463,7 @@ bool slab3d_supported(int Cout, int C0, int C1, int stride, int arith) {
     return slab3d_dispatch(Cout, C0 + C1, stride, [](auto) {});
 }
 
-// packed: [A fragments (KT x MT x 2 x 64 x 16 B) | scale (Cout) | shift (Cout) | oscale]
+// packed: [A fragments (KT x MT x 2 x 64 x 16 B) | scale (Cout) | shift (Cout) | oscale, xscale, amax, 2^-s (split_arith.h: SPLIT_TAIL_*)]
 int64_t slab3d_packed_floats(int Cout, int Ct, int stride) {
     int64_t frag = 0;
     slab3d_dispatch(Cout, Ct, stride, [&](auto S) { frag = (int64_t)decltype(S)::KT * decltype(S)::MT; });
@@ -488,7 +489,11 @@ void slab3d_pack(int Cout, int Ct, int stride, const float* w /* (Cout, Ct, 3,3,
         tail[co] = scale[co];
         tail[Cout + co] = shift[co];
     }
-    tail[2 * Cout] = std::ldexp(1.f, -(sft + SPLIT_F16_XSHIFT));
+    float* st = tail + 2 * Cout;  // split_arith.h: SPLIT_TAIL_*
+    st[SPLIT_TAIL_OSCALE] = std::ldexp(1.f, -(sft + SPLIT_F16_XSHIFT));
+    st[SPLIT_TAIL_XSCALE] = std::ldexp(1.f, SPLIT_F16_XSHIFT);
+    st[SPLIT_TAIL_AMAX] = 0.f;
+    st[SPLIT_TAIL_WSINV] = std::ldexp(1.f, -sft);
 }
 
 int slab3d_forward(int Cout, int C0, int C1, int stride, const float* packed, const float* x0, const float* x1, float* y, int N, int D,
@@ -509,6 +514,12 @@ int slab3d_forward(int Cout, int C0, int C1, int stride, const float* packed, co
     a.D = D; a.H = H; a.W = W;
     a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     a.slope = slope;
+    if (calibrating()) {  // record the largest |x| of the volumes this launch stages (calib.hip); the zero end slices do not matter
+        const float* tail = a.scale + 2 * Cout;
+        if (int rc2 = calib_amax_flat(x0, (int64_t)N * (D + 2) * C0 * H * W, tail, s)) return rc2;
+        if (C1 > 0)
+            if (int rc2 = calib_amax_flat(x1, (int64_t)N * (D + 2) * C1 * H * W, tail, s)) return rc2;
+    }
     int rc = NND_ERR_INVALID;
     slab3d_dispatch(Cout, Ct, stride, [&](auto S) { rc = launch_slab3d<decltype(S)::CIN_, decltype(S)::COUT_, decltype(S)::STR_>(a, N, s); });
     return rc;

@@ -60,6 +60,9 @@ static ConvLayer mk(int KH, int KW, int Cin, int Cout, int64_t* off, int arith =
 
 static int make_plan(const nnd_update_block_desc* d, Plan* p) {
     NND_REQUIRE(d, "update_block: null descriptor");
+    NND_REQUIRE(d->struct_size == (int32_t)sizeof(nnd_update_block_desc), "update_block: descriptor of %d bytes, this library expects %d (struct_size)",
+                d->struct_size, (int)sizeof(nnd_update_block_desc));
+    NND_REQUIRE((d->flags & ~NND_FLAG_CALIBRATE) == 0, "update_block: unknown flags 0x%x", d->flags);
     const int hid = d->hidden_dim, ctx = d->context_dim, cp = d->cor_planes, fc = d->flow_channels, mc = d->mask_channels;
     NND_REQUIRE(hid > 0 && hid % 32 == 0, "update_block: hidden_dim %d must be a positive multiple of 32", hid);
     NND_REQUIRE(ctx > 0 && ctx % 8 == 0, "update_block: context_dim %d must be a positive multiple of 8", ctx);
@@ -69,10 +72,9 @@ static int make_plan(const nnd_update_block_desc* d, Plan* p) {
                 "update_block: arithmetic must be 0 (fp32 MFMA), 3 (bf16x3 split) or 2 (fp16x2 split)");
     // arithmetic == 3: every MFMA conv whose shape conv_split.hip builds takes the split-bf16 kernel (mask.2 inside the fused
     // mask + upsample kernel; convf2 together with convf1 in flow_branch_kernel), except convc1 (its weights are consumed by the
-    // fused lookup kernels in the fp32 packing); NND_SPLIT_MASK (diagnostic) restricts it to a subset, bit = ConvId (e.g. 2 =
-    // encoder.convc2 only)
-    // (read once at library load, so the packed-blob layout cannot change between pack and forward)
-    const unsigned split_mask = switches().split_mask;
+    // fused lookup kernels in the fp32 packing); desc.split_layers (diagnostic) restricts it to a subset, bit = ConvId (e.g. 2 =
+    // encoder.convc2 only) — part of the descriptor, so the blob layout is a function of the descriptor alone
+    const unsigned split_mask = d->split_layers ? (unsigned)d->split_layers : ~0u;
     auto ar = [&](int id) { return (d->arithmetic != 0 && ((split_mask >> id) & 1u)) ? d->arithmetic : 0; };
     p->d = *d;
     p->sep = d->gru_kind == 0;
@@ -511,6 +513,17 @@ static int run_fc2(const Plan& p, const float* blob, const Bufs& w, float* delta
     return debug_sync("flow_head.conv2", s);
 }
 
+// Calibration of the fused flow branch (calib.hip): what convf2 stages there is relu(convf1(flow)), which the fused kernel keeps in
+// LDS — under NND_FLAG_CALIBRATE the stand-alone convf1 kernel writes it to w.f1 (unused otherwise on this path) and its largest
+// value is recorded in convf2's slot.
+static int calib_flow_branch(const Plan& p, const float* blob, const Bufs& w, const float* flow, int B, int H, int W, hipStream_t s) {
+    if (!calibrating() || p.L[C_F2].arith != 2) return NND_OK;
+    const int64_t n = tiled_plane(H, W);
+    int rc = run_convf1(p, blob, flow, (int64_t)p.d.flow_channels * n, w.f1, B, H, W, s);
+    if (rc != NND_OK) return rc;
+    return calib_amax_act(Act{w.f1, 128 * n, 128}, make_lay(H, W, true), B, H, W, blob + p.L[C_F2].tail_off(), s);
+}
+
 // Flow branch of the motion encoder: convf1 (7x7 on the flow) -> convf2 (3x3) -> cf[192:256].  Split arithmetic: one launch
 // (conv_split.hip: flow_branch_kernel), the 128-channel intermediate never reaches HBM; exact arithmetic, or
 // NND_NO_FUSED_FLOW_BRANCH (which the parity test toggles): convf1_kernel into w.f1, then the conv.
@@ -519,6 +532,7 @@ static int run_flow_branch(const Plan& p, const float* blob, const Bufs& w, cons
     const int fc = p.d.flow_channels;
     const int64_t n = tiled_plane(H, W);
     if (flow_branch_supported(p.L[C_F2], fc) && !switches().no_fused_flow_branch) {
+        if (int rc0 = calib_flow_branch(p, blob, w, flow, B, H, W, s)) return rc0;
         const ConvIO io = conv_io(p, w, C_F2, corr, n, nullptr, nullptr);
         int rc = launch_flow_branch(p.L[C_F2], blob, blob + p.f1_wt, blob + p.f1_b, flow, (int64_t)fc * n, fc, io, B, H, W, s);
         if (rc != NND_OK) return rc;
@@ -657,6 +671,26 @@ int nnd_update_block_pack(const nnd_update_block_desc* desc, const float* const*
     return NND_OK;
 }
 
+int nnd_update_block_scale_slots(const nnd_update_block_desc* desc, int64_t* offsets, int n) {
+    Plan p;
+    int rc = make_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    for (int i = 0; offsets && i < n && i < C_COUNT; ++i) offsets[i] = p.L[i].arith == 2 ? p.L[i].tail_off() : -1;
+    return C_COUNT;
+}
+
+int nnd_update_block_calibration_finish(const nnd_update_block_desc* desc, float* packed_dev, int32_t* status_dev, void* stream) {
+    Plan p;
+    int rc = make_plan(desc, &p);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev, "update_block_calibration_finish: null blob");
+    int64_t offs[C_COUNT];
+    int n = 0;
+    for (int i = 0; i < C_COUNT; ++i)
+        if (p.L[i].arith == 2 && (p.sep || (i != C_ZR2 && i != C_Q2 && i != C_ZR2X && i != C_Q2X && i != C_ZR2C && i != C_Q2C))) offs[n++] = p.L[i].tail_off();
+    return calib_finish(packed_dev, offs, n, status_dev, (hipStream_t)stream);
+}
+
 int64_t nnd_update_block_workspace_floats(const nnd_update_block_desc* desc, int B, int H, int W) {
     Plan p;
     if (make_plan(desc, &p) != NND_OK || B <= 0 || H <= 0 || W <= 0) return NND_ERR_INVALID;
@@ -673,6 +707,7 @@ int nnd_update_block_forward(const nnd_update_block_desc* desc, const float* pac
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && net && inp && corr && flow && net_out && delta_out && workspace, "update_block_forward: null pointer");
     NND_REQUIRE(B > 0 && H > 0 && W > 0, "update_block_forward: bad shape");
+    CalibScope calib((p.d.flags & NND_FLAG_CALIBRATE) && p.d.arithmetic == 2);
     hipStream_t s = (hipStream_t)stream;
     Bufs w;
     carve(p, B, H, W, workspace, &w);
@@ -754,6 +789,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
 
     NND_REQUIRE(p.d.mask_channels == 9 * rate * rate, "raft_stereo_refine: mask_channels %d != 9*rate^2", p.d.mask_channels);
     NND_REQUIRE(B > 0 && H > 0 && W > 0 && iters > 0, "raft_stereo_refine: bad shape");
+    CalibScope calib((p.d.flags & NND_FLAG_CALIBRATE) && p.d.arithmetic == 2);
     hipStream_t s = (hipStream_t)stream;
     Bufs w;
     carve(p, B, H, W, workspace, &w);
@@ -825,11 +861,16 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
         probe_mark(id, s);
         return rc_;
     };
+    // IGEV, fp16x2 convc1 inside the interleaved lookup: its operands are interpolated from the interleaved pyramid, whose largest
+    // value bounds them (the sampler is a convex combination of two entries)
+    if (calibrating() && fused_lk && interleaved && p.L[C_C1].arith == 2 && igev_lookup_convc1_il_supported(groups, num_levels, radius))
+        NND_TRY(calib_amax_flat(interleaved, nnd_igev_interleaved_floats(B, groups, H, W, num_levels), packed + p.L[C_C1].tail_off(), s));
     for (int it = 0; it < iters; ++it) {
         // RAFT-Stereo, arithmetic 2: the flow branch and lookup + convc1 — independent of each other — as ONE launch of two
         // kinds of workgroups that share every CU (corr1d.hip: flow_branch_lookup_kernel)
         if (merged_fbl) {
             probe_mark(C_F2, s);
+            NND_TRY(calib_flow_branch(p, packed, w, w.flow, B, H, W, s));
             const ConvIO fio = conv_io(p, w, C_F2, c, n, nullptr, nullptr);
             NND_TRY(flow_branch_lookup_launch(p.L[C_F2], packed, packed + p.f1_wt, packed + p.f1_b, w.flow, (int64_t)fc * n, fc, fio, pyramid,
                                               w.coords, p.L[C_C1], w.c1, 256 * n, B, H, W, num_levels, radius, s, ws_c4()));
@@ -921,6 +962,20 @@ int nnd_conv2d_forward_ex(const float* packed_dev, const float* x, float* y, int
     io.out0 = act(y, Cout * n, Cout);
     return launch_conv(L, packed_dev, io, relu ? EPI_RELU : EPI_LINEAR, B, H, W, (hipStream_t)stream);
 }
+int nnd_conv2d_calibrate_ex(float* packed_dev, const float* x, int B, int Cin, int H, int W, int Cout, int KH, int KW, int arithmetic,
+                            int32_t* status_dev, void* stream) {
+    ConvLayer L;
+    int rc = conv2d_layer(Cout, Cin, KH, KW, arithmetic, &L, nullptr);
+    if (rc != NND_OK) return rc;
+    NND_REQUIRE(packed_dev && x && B > 0 && H > 0 && W > 0, "conv2d_calibrate: bad argument");
+    if (L.arith != 2) return NND_OK;
+    const int64_t n = (int64_t)H * W;
+    rc = calib_amax_act(act(const_cast<float*>(x), Cin * n, Cin), make_lay(H, W, false), B, H, W, packed_dev + L.tail_off(), (hipStream_t)stream);
+    if (rc != NND_OK) return rc;
+    const int64_t off = L.tail_off();
+    return calib_finish(packed_dev, &off, 1, status_dev, (hipStream_t)stream);
+}
+
 int nnd_conv2d_forward(const float* packed_dev, const float* x, float* y, int B, int Cin, int H, int W, int Cout, int KH,
                        int KW, int relu, void* stream) {
     return nnd_conv2d_forward_ex(packed_dev, x, y, B, Cin, H, W, Cout, KH, KW, relu, 0, stream);

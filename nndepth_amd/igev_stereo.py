@@ -28,7 +28,7 @@ from . import ops
 from ._lib import NndError
 from .blocks import BasicUpdateBlock
 from .cost_volume import GeometryAwareCostVolume
-from .raft_stereo import load_weights, require_eval
+from .raft_stereo import AutoCalibrate, load_weights, require_eval
 from .upsample import convex_upsample
 
 
@@ -156,7 +156,7 @@ class CostVolumeFilterNetwork(nn.Module):
 
 
 # ------------------------------------------------------------------ the model
-class IGEVStereoBase(nn.Module):
+class IGEVStereoBase(AutoCalibrate, nn.Module):
     def __init__(self, update_cls: str = "basic_update_block", cv_groups: int = 8, iters: int = 12, hidden_dim: int = 128,
                  context_dim: int = 128, corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
@@ -212,7 +212,7 @@ class IGEVStereoBase(nn.Module):
     def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
         require_eval(self)
         with torch.no_grad():
-            return self._forward(frame1, frame2)
+            return self._forward_calibrated(frame1, frame2)
 
     def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
         fmap1, fmap2, cnet1, guide_features = self.forward_fnet(frame1, frame2)

@@ -4,12 +4,15 @@ PyTorch is plumbing only: it owns device memory and the HIP stream; every comput
 call into libnndepth_amd.so.  All ops require fp32 tensors on a HIP ("cuda") device and
 raise otherwise — there is no CPU or eager fallback.
 """
+import contextlib
 import ctypes as C
-from typing import List, Optional, Sequence, Tuple
+import os
+import threading
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import Conv3dDesc, ConvDesc, EncoderDesc, NndError, UpdateBlockDesc, check, lib
+from ._lib import NND_FLAG_CALIBRATE, Conv3dDesc, ConvDesc, EncoderDesc, NndError, UpdateBlockDesc, check, lib
 
 
 def _dev(*tensors: torch.Tensor) -> torch.device:
@@ -31,6 +34,75 @@ def _stream(device: torch.device) -> C.c_void_p:
 
 def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ------------------------------------------------------------- fp16x2 activation-range calibration
+# include/nndepth_amd.h "fp16x2 activation range", csrc/calib.hip.  Inside `with calibration() as c:` every engine call made by
+# this thread carries NND_FLAG_CALIBRATE (the layers record the largest |activation| they stage); leaving the block fixes the
+# per-layer activation scales of every engine that ran (`nnd_*_calibration_finish`, on the stream, no synchronisation) —
+# reading `c.status` afterwards synchronises: bit 0 = a layer saw inf / NaN at its old scale (run the block again), bit 1 = some
+# fp16x2 layer of an engine was not on the path.
+_calib_tls = threading.local()
+
+
+class _Calibration:
+    def __init__(self):
+        self.engines: List[object] = []
+        self._status: Optional[torch.Tensor] = None
+
+    def flags(self, engine) -> int:
+        """Called by an engine for each C-ABI call it makes: registers the engine, returns the flag word of the descriptor."""
+        if all(e is not engine for e in self.engines):
+            self.engines.append(engine)
+        return NND_FLAG_CALIBRATE
+
+    @property
+    def status(self) -> int:
+        return 0 if self._status is None else int(self._status.item())
+
+
+class NeedsCalibration(NndError):
+    """Raised inside `with require_calibrated()` by an fp16x2 engine whose activation scales are still the defaults."""
+
+
+def _calib_flags(engine) -> int:
+    c = getattr(_calib_tls, "active", None)
+    if c is not None:
+        return c.flags(engine)
+    if getattr(_calib_tls, "require", False) and not engine.calibrated:
+        raise NeedsCalibration(f"{type(engine).__name__}: fp16x2 activation scales not calibrated")
+    return 0
+
+
+@contextlib.contextmanager
+def require_calibrated():
+    """Inside the block an fp16x2 engine that has not been calibrated since its parameters were packed raises NeedsCalibration
+    instead of running with the default activation scales (the model classes use it to calibrate on their first forward)."""
+    old = getattr(_calib_tls, "require", False)
+    _calib_tls.require = True
+    try:
+        yield
+    finally:
+        _calib_tls.require = old
+
+
+@contextlib.contextmanager
+def calibration():
+    if getattr(_calib_tls, "active", None) is not None:
+        raise NndError("calibration(): already active on this thread")
+    c = _Calibration()
+    _calib_tls.active = c
+    try:
+        yield c
+    finally:
+        _calib_tls.active = None
+    for e in c.engines:
+        d = e.packed.device
+        if c._status is None:
+            c._status = torch.zeros(1, dtype=torch.int32, device=d)
+        with torch.cuda.device(d):
+            e._calibration_finish(c._status)
+        e.calibrated = True
 
 
 # ---------------------------------------------------------------------------- correlation
@@ -99,6 +171,29 @@ class Conv2d:
         check(lib.nnd_conv2d_pack_ex(_p(w), _p(b), self.Cout, self.Cin, self.KH, self.KW, self.arith, _p(blob)), "conv2d_pack")
         self.packed_host = blob
         self.packed = blob.to(device) if device is not None else None
+        self.calibrated = False
+
+    def calibrate(self, x: torch.Tensor) -> "Conv2d":
+        """fp16x2: set the layer's activation scale from the largest |x| of this input (include/nndepth_amd.h
+        "fp16x2 activation range"); the other arithmetics have no range to calibrate."""
+        d = _dev(x, self.packed)
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        if Cin != self.Cin:
+            raise NndError(f"conv2d: input has {Cin} channels, weights expect {self.Cin}")
+        with torch.cuda.device(d):
+            check(lib.nnd_conv2d_calibrate_ex(_p(self.packed), _p(x), B, Cin, H, W, self.Cout, self.KH, self.KW, self.arith, None,
+                                              _stream(d)), "conv2d_calibrate")
+        self.calibrated = True
+        return self
+
+    def activation_range(self) -> float:
+        """Largest |x| the layer represents (fp16x2: 65504 / its activation scale; inf otherwise)."""
+        if self.arith != 2:
+            return float("inf")
+        ncb = (self.Cout + 31) // 32
+        n = self.packed.numel()
+        return 65504.0 / float(self.packed[n - 4 + 1].item()) if ncb else float("inf")
 
     def __call__(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
         d = _dev(x, self.packed)
@@ -106,6 +201,11 @@ class Conv2d:
         B, Cin, H, W = x.shape
         if Cin != self.Cin:
             raise NndError(f"conv2d: input has {Cin} channels, weights expect {self.Cin}")
+        if self.arith == 2:
+            if getattr(_calib_tls, "active", None) is not None:  # inside `with calibration()`: a single layer calibrates on the spot
+                self.calibrate(x)
+            else:
+                _calib_flags(self)  # raises inside `with require_calibrated()` if the scale is still the default
         y = torch.empty((B, self.Cout, H, W), dtype=torch.float32, device=d)
         with torch.cuda.device(d):
             check(lib.nnd_conv2d_forward_ex(_p(self.packed), _p(x), _p(y), B, Cin, H, W, self.Cout, self.KH, self.KW,
@@ -204,8 +304,12 @@ class UpdateBlockEngine:
                            "fp16x2 = 2-piece range-scaled split on the fp16 MFMA)")
         self.gru = gru
         self.arithmetic = arithmetic
+        # split_layers: diagnostic subset of the convolutions that take the split arithmetic (bit = index in conv_names();
+        # part of the blob layout, so it lives in the descriptor) — NND_SPLIT_MASK is read here, once, by the bisecting scripts
         self.desc = UpdateBlockDesc(hidden_dim, context_dim, cor_planes, flow_channels, mask_channels,
-                                    0 if gru == "sep_conv" else 1, self.ARITHMETIC[arithmetic])
+                                    0 if gru == "sep_conv" else 1, self.ARITHMETIC[arithmetic],
+                                    int(os.environ.get("NND_SPLIT_MASK", "0"), 0) & 0x7fffffff, 0)
+        self.calibrated = False
         n = lib.nnd_update_block_packed_floats(C.byref(self.desc))
         if n <= 0:
             check(int(n), "update_block_packed_floats")
@@ -226,7 +330,33 @@ class UpdateBlockEngine:
 
     def load(self, state: dict, prefix: str = "", device="cuda") -> "UpdateBlockEngine":
         self.packed = self.pack_host(state, prefix).to(device)
+        self.calibrated = False  # a fresh blob carries the default activation scales
         return self
+
+    # ---- fp16x2 activation range (include/nndepth_amd.h "fp16x2 activation range")
+    def _desc(self):
+        """The descriptor for one C-ABI call: carries NND_FLAG_CALIBRATE inside `with ops.calibration()`."""
+        self.desc.flags = _calib_flags(self) if self.arithmetic == "fp16x2" else 0
+        return C.byref(self.desc)
+
+    def _calibration_finish(self, status: Optional[torch.Tensor]) -> None:
+        self.desc.flags = 0
+        check(lib.nnd_update_block_calibration_finish(C.byref(self.desc), _p(self.packed), _p(status), _stream(self.packed.device)),
+              "update_block_calibration_finish")
+
+    def activation_ranges(self) -> Dict[str, float]:
+        """{convolution: largest |activation| its fp16x2 operands represent} (65504 / the layer's activation scale)."""
+        self.desc.flags = 0
+        n = int(lib.nnd_update_block_scale_slots(C.byref(self.desc), None, 0))
+        offs = (C.c_int64 * n)()
+        check(min(0, int(lib.nnd_update_block_scale_slots(C.byref(self.desc), offs, n))), "update_block_scale_slots")
+        blob = self.packed.cpu() if self.packed is not None else None
+        out = {}
+        for i in range(n):
+            if offs[i] >= 0 and blob is not None:
+                name = lib.nnd_conv_name(C.byref(self.desc), i).decode()
+                out[name or f"conv{i}"] = 65504.0 / float(blob[offs[i] + 1])
+        return out
 
     # ---- workspace
     def workspace(self, B: int, H: int, W: int, device) -> torch.Tensor:
@@ -266,7 +396,7 @@ class UpdateBlockEngine:
         delta = torch.empty_like(flow)
         ws = self.workspace(B, H, W, d)
         with torch.cuda.device(d):
-            check(lib.nnd_update_block_forward(C.byref(ds), _p(self.packed), _p(net), _p(inp), _p(corr), _p(flow),
+            check(lib.nnd_update_block_forward(self._desc(), _p(self.packed), _p(net), _p(inp), _p(corr), _p(flow),
                                                _p(net_out), _p(mask), _p(delta), _p(ws), B, H, W, _stream(d)),
                   "update_block_forward")
         return net_out, mask, delta
@@ -294,7 +424,7 @@ class UpdateBlockEngine:
         if disp_init is not None:
             disp_init = disp_init.contiguous()
         with torch.cuda.device(d):
-            check(lib.nnd_raft_stereo_refine(C.byref(self.desc), _p(self.packed), _p(pyr), num_levels, radius,
+            check(lib.nnd_raft_stereo_refine(self._desc(), _p(self.packed), _p(pyr), num_levels, radius,
                                              _p(net), _p(inp), _p(disp_init), _p(up), stride, _p(low), _p(net_out),
                                              _p(ws), B, H, W, rate, iters, _stream(d)), "raft_stereo_refine")
         return up, low, net_out
@@ -329,7 +459,7 @@ class UpdateBlockEngine:
         if disp_init is not None:
             disp_init = disp_init.contiguous()
         with torch.cuda.device(d):
-            check(lib.nnd_igev_stereo_refine(C.byref(self.desc), _p(self.packed), _p(feat_pyr), _p(geo_pyr), _p(interleaved), num_groups,
+            check(lib.nnd_igev_stereo_refine(self._desc(), _p(self.packed), _p(feat_pyr), _p(geo_pyr), _p(interleaved), num_groups,
                                              num_levels, radius, _p(net), _p(inp), _p(disp_init), _p(up), stride, _p(low),
                                              _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "igev_stereo_refine")
         return up, low, net_out
@@ -364,7 +494,7 @@ class UpdateBlockEngine:
         if scratch is None or scratch.numel() < need:
             scratch = torch.empty(need, dtype=torch.float32, device=d)
         with torch.cuda.device(d):
-            check(lib.nnd_cre_stereo_refine(C.byref(self.desc), _p(self.packed), _p(fmap1), _p(fmap2), Cf, _p(extra_offset),
+            check(lib.nnd_cre_stereo_refine(self._desc(), _p(self.packed), _p(fmap1), _p(fmap2), Cf, _p(extra_offset),
                                             _p(scratch), scratch.numel(), _p(net), _p(inp), _p(flow_init), _p(up), stride, _p(low),
                                             _p(net_out), _p(ws), B, H, W, rate, iters, _stream(d)), "cre_stereo_refine")
         return up, low, net_out
@@ -608,8 +738,10 @@ class EncoderEngine:
         if norm not in ("batch", "none", "instance"):
             raise NndError(f"EncoderEngine: norm_fn '{norm}' is not built in HIP (batch in eval mode, instance, none)")
         self.norm = norm
+        self.arithmetic = arithmetic
         self.desc = EncoderDesc(int(output_dim), {"none": 0, "batch": 1, "instance": 2}[norm], int(cnet_dim),
-                                UpdateBlockEngine.ARITHMETIC[arithmetic])
+                                UpdateBlockEngine.ARITHMETIC[arithmetic], 0)
+        self.calibrated = False
         n = int(lib.nnd_encoder_packed_floats(C.byref(self.desc)))
         if n <= 0:
             check(n, "encoder_packed_floats")
@@ -644,7 +776,13 @@ class EncoderEngine:
         blob = torch.empty(self.packed_floats, dtype=torch.float32)
         check(lib.nnd_encoder_pack(C.byref(self.desc), arr, float(eps), _p(blob)), "encoder_pack")
         self.packed = blob.to(device)
+        self.calibrated = False
         return self
+
+    def _calibration_finish(self, status: Optional[torch.Tensor]) -> None:
+        self.desc.flags = 0
+        check(lib.nnd_encoder_calibration_finish(C.byref(self.desc), _p(self.packed), _p(status), _stream(self.packed.device)),
+              "encoder_calibration_finish")
 
     def forward(self, frames: torch.Tensor, n_cnet: int = 0):
         """frames (N,3,H,W) -> (fmap (N,output_dim,H/8,W/8), cnet (n_cnet,cnet_dim,H/8,W/8) or None)."""
@@ -663,6 +801,7 @@ class EncoderEngine:
         need = int(lib.nnd_encoder_workspace_floats(C.byref(self.desc), N, H, W))
         if self._ws is None or self._ws.numel() < need or self._ws.device != d:
             self._ws = torch.empty(need, dtype=torch.float32, device=d)
+        self.desc.flags = _calib_flags(self) if self.arithmetic == "fp16x2" else 0
         with torch.cuda.device(d):
             check(lib.nnd_encoder_forward(C.byref(self.desc), _p(self.packed), _p(frames), _p(fmap), _p(cnet), n_cnet,
                                           _p(self._ws), N, H, W, _stream(d)), "encoder_forward")
@@ -801,7 +940,9 @@ class Conv3dNorm:
         if tuple(weight.shape[2:]) != (3, 3, 3):
             raise NndError("Conv3dNorm: only 3x3x3 kernels")
         cin0 = split if split > 0 else Cin
-        self.desc = Conv3dDesc(Cout, cin0, Cin - cin0, int(stride), UpdateBlockEngine.ARITHMETIC[arithmetic])
+        self.arithmetic = arithmetic
+        self.desc = Conv3dDesc(Cout, cin0, Cin - cin0, int(stride), UpdateBlockEngine.ARITHMETIC[arithmetic], 0)
+        self.calibrated = False
         self.leaky = float(leaky_slope)
         n = int(lib.nnd_conv3d_packed_floats(C.byref(self.desc)))
         if n <= 0:
@@ -811,6 +952,11 @@ class Conv3dNorm:
         blob = torch.empty(n, dtype=torch.float32)
         check(lib.nnd_conv3d_pack(C.byref(self.desc), _p(w), _p(b), _p(g), _p(be), _p(m), _p(v), float(eps), _p(blob)), "conv3d_pack")
         self.packed = blob.to(device)
+
+    def _calibration_finish(self, status: Optional[torch.Tensor]) -> None:
+        self.desc.flags = 0
+        check(lib.nnd_conv3d_calibration_finish(C.byref(self.desc), _p(self.packed), _p(status), _stream(self.packed.device)),
+              "conv3d_calibration_finish")
 
     def __call__(self, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
         d = _dev(x0, self.packed)
@@ -826,6 +972,7 @@ class Conv3dNorm:
         st, D = self.desc.stride, Dp - 2
         Do, Ho, Wo = (D + st - 1) // st, (H + st - 1) // st, (W + st - 1) // st
         y = torch.empty((N, Do + 2, self.desc.Cout, Ho, Wo), dtype=torch.float32, device=d)
+        self.desc.flags = _calib_flags(self) if self.arithmetic == "fp16x2" else 0
         with torch.cuda.device(d):
             check(lib.nnd_conv3d_forward(C.byref(self.desc), _p(self.packed), _p(x0), _p(x1), _p(y), N, D, H, W, self.leaky,
                                          _stream(d)), "conv3d_forward")

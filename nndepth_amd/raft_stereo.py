@@ -52,6 +52,45 @@ def require_eval(model: nn.Module) -> None:
                        "(training-mode BatchNorm / autograd are not built)")
 
 
+class AutoCalibrate:
+    """fp16x2 activation range (include/nndepth_amd.h "fp16x2 activation range", csrc/calib.hip), shared by the model classes.
+
+    The fp16x2 arithmetic carries an activation x as two fp16 pieces of x * 2^xs with xs per layer.  A freshly packed layer has
+    xs = 2 (all 22 bits for 0.06 <= |x| < 16376); `calibrate(frame1, frame2)` runs the forward once with every layer recording the
+    largest |activation| M it stages and then sets xs so that M * 2^xs lies in [2^10, 2^11): all 22 bits from M down to M * 2^-13,
+    absolute error <= M * 2^-36 below, finite results up to 32 * M, inf / NaN in the output beyond (never a silently wrong value).
+    With `auto_calibrate` (default) the first `forward()` after the parameters were (re)packed calibrates on its own input — one
+    extra forward, once; call `calibrate()` yourself with representative frames to choose the data, or set
+    `auto_calibrate = False` to keep the default scales.  `activation_ranges()` reports the valid |x| per update-block layer."""
+
+    auto_calibrate = True
+
+    def calibrate(self, *args, max_passes: int = 4, **kwargs):
+        require_eval(self)
+        for _ in range(max_passes):
+            with ops.calibration() as c, torch.no_grad():
+                self._forward(*args, **kwargs)
+            if not (c.status & 1):  # bit 0: a layer saw inf / NaN at the scale it had (lowered by 2^12 since): go again
+                return self
+        raise NndError(f"{type(self).__name__}.calibrate: activations still overflow fp16 after {max_passes} passes "
+                       "(non-finite inputs or weights?)")
+
+    def _forward_calibrated(self, *args, **kwargs):
+        """`_forward`, calibrating first if an fp16x2 engine on its path still has the default activation scales."""
+        if self.arithmetic != "fp16x2" or not self.auto_calibrate:
+            return self._forward(*args, **kwargs)
+        try:
+            with ops.require_calibrated():
+                return self._forward(*args, **kwargs)
+        except ops.NeedsCalibration:
+            self.calibrate(*args, **kwargs)
+            return self._forward(*args, **kwargs)
+
+    def activation_ranges(self):
+        eng = self.update_block.engine
+        return eng.activation_ranges() if eng.packed is not None else {}
+
+
 def hip_encoder_blocker(fnet: nn.Module, norms) -> Optional[str]:
     """Why csrc/encoder.hip cannot run this BasicEncoder, or None."""
     if fnet.norm_fn not in norms:
@@ -61,7 +100,7 @@ def hip_encoder_blocker(fnet: nn.Module, norms) -> Optional[str]:
     return None
 
 
-class BaseRAFTStereo(nn.Module):
+class BaseRAFTStereo(AutoCalibrate, nn.Module):
     def __init__(self, iters: int = 12, fnet_dim: int = 256, hidden_dim: int = 128, context_dim: int = 128,
                  corr_levels: int = 4, corr_radius: int = 4, tracing: bool = False,
                  include_preprocessing: bool = False, weights: Optional[str] = None, strict_load: bool = True,
@@ -119,7 +158,7 @@ class BaseRAFTStereo(nn.Module):
     def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
         require_eval(self)
         with torch.no_grad():
-            return self._forward(frame1, frame2)
+            return self._forward_calibrated(frame1, frame2)
 
     def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
         fmap1, fmap2, cnet = self.forward_fnet(frame1, frame2)
@@ -165,3 +204,14 @@ def patch(model: nn.Module, arithmetic: str = "fp16x2") -> nn.Module:
     model.corr_fn = CorrBlock1D
     model.convex_upsample = lambda flow, mask, rate=8: convex_upsample(flow, mask, rate)
     return model
+
+
+def calibrate_patched(model: nn.Module, frame1: torch.Tensor, frame2: torch.Tensor, max_passes: int = 4) -> nn.Module:
+    """fp16x2 activation-range calibration of a `patch()`ed reference model on one pair (see AutoCalibrate): the reference's own
+    forward runs inside `ops.calibration()`, so the seams record what they stage."""
+    for _ in range(max_passes):
+        with ops.calibration() as c, torch.no_grad():
+            model(frame1, frame2)
+        if not (c.status & 1):
+            return model
+    raise NndError("calibrate_patched: activations still overflow fp16")

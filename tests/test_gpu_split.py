@@ -46,6 +46,126 @@ def test_split_conv_vs_float64(shape, arith):
     assert (yr - truth.clamp_min(0)).abs().max().item() <= 2e-5 * max(1.0, scale / 4)
 
 
+# ---- round 4: the activation range of fp16x2.  Two fp16 pieces of x * 2^xs only carry their 22 bits while
+# x * 2^xs sits inside fp16's normal range; xs is per layer and calibrated from data (csrc/calib.hip, include/nndepth_amd.h
+# "fp16x2 activation range").  The sweep: inputs scaled by 2^-12 ... 2^+12, Gaussian and heavy-tailed (1 % of the elements x 256),
+# the same assertion as test_split_conv_vs_float64 relative to the output's scale.
+SCALE_EXPS = [-12, -8, -4, 0, 4, 8, 12]
+SWEEP_SHAPES = [(192, 256, 3, 3, 1, 68, 120), (256, 256, 1, 5, 1, 34, 60), (96, 320, 1, 5, 2, 9, 33), (576, 256, 1, 1, 1, 8, 12)]
+
+
+def _sweep_input(shape, k, kind):
+    Cout, Cin, KH, KW, B, H, W = shape
+    g = torch.Generator().manual_seed(Cout + Cin + H + 7 * k + (1000 if kind == "heavy" else 0))
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    x = torch.randn(B, Cin, H, W, generator=g) * 3.0
+    if kind == "heavy":  # 1 % of the elements 256 x larger: the tensor's maximum sits 8 octaves above its bulk
+        x = torch.where(torch.rand(x.shape, generator=g) < 0.01, x * 256.0, x)
+    x = x * 2.0 ** k
+    b = torch.randn(Cout, generator=g) * 2.0 ** k
+    return w, b, x
+
+
+@pytest.mark.parametrize("kind", ["gauss", "heavy"])
+@pytest.mark.parametrize("k", SCALE_EXPS, ids=lambda k: f"2^{k}")
+@pytest.mark.parametrize("shape", SWEEP_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("arith", ARITHS)
+def test_split_conv_vs_float64_over_input_scales(shape, arith, k, kind):
+    """Per-op error of the split kernels (fp16x2 calibrated on the input, as the model classes do on their first forward) against
+    float64 over 24 octaves of input scale: at the level of the exact fp32 kernel's own rounding error at every scale."""
+    from nndepth_amd import ops
+    Cout, Cin, KH, KW, B, H, W = shape
+    w, b, x = _sweep_input(shape, k, kind)
+    truth = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=(KH // 2, KW // 2))
+    oscale = truth.abs().max().item()
+    y32 = ops.Conv2d(w, b)(x.to(DEV)).cpu().double()
+    conv = ops.Conv2d(w, b, arithmetic=arith)
+    conv.calibrate(x.to(DEV))
+    ysp = conv(x.to(DEV)).cpu().double()
+    assert torch.isfinite(ysp).all()
+    e32, esp = (y32 - truth).abs().max().item(), (ysp - truth).abs().max().item()
+    r32, rsp = (y32 - truth).pow(2).mean().sqrt().item(), (ysp - truth).pow(2).mean().sqrt().item()
+    print(f"\n{shape} x 2^{k} {kind}: max-abs / |y|max  fp32-MFMA {e32 / oscale:.2e}  {arith} {esp / oscale:.2e}   rms {r32 / oscale:.2e} / {rsp / oscale:.2e}"
+          f"   valid |x| < {conv.activation_range():.3g} (|x| max {x.abs().max().item():.3g})")
+    assert esp <= 1.25 * e32 + 2e-7 * oscale and rsp <= 1.05 * r32 + 2e-8 * oscale and esp <= 5e-6 * oscale
+
+
+def test_fp16x2_uncalibrated_small_activations_are_what_calibration_fixes():
+    """The gap itself: with the default activation scale (x 4) a tensor of values around 1e-3 loses the low
+    fp16 piece to subnormals and the error is well above the exact kernel's; calibrated, it is back at that level."""
+    from nndepth_amd import ops
+    shape = (192, 256, 3, 3, 1, 68, 120)
+    w, b, x = _sweep_input(shape, -12, "gauss")
+    truth = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    e32 = (ops.Conv2d(w, b)(x.to(DEV)).cpu().double() - truth).abs().max().item()
+    conv = ops.Conv2d(w, b, arithmetic="fp16x2")
+    e_default = (conv(x.to(DEV)).cpu().double() - truth).abs().max().item()
+    e_calib = (conv.calibrate(x.to(DEV))(x.to(DEV)).cpu().double() - truth).abs().max().item()
+    print(f"\nfp16x2 at |x| ~ {x.abs().max().item():.1e}: default scale {e_default:.2e}, calibrated {e_calib:.2e}, exact fp32 kernel {e32:.2e}")
+    assert e_default > 4 * e32 and e_calib <= 1.25 * e32
+
+
+def test_fp16x2_out_of_range_activations_are_visible():
+    """What include/nndepth_amd.h promises beyond the valid range: inf / NaN in the output, never a finite wrong value.  Default
+    scale: valid below 16376.  Calibrated at maximum M: finite up to 32 M (here 16 M), non-finite beyond (here 64 M)."""
+    from nndepth_amd import ops
+    torch.manual_seed(3)
+    w = torch.randn(64, 128, 3, 3) / (128 * 9) ** 0.5
+    b = torch.zeros(64)
+    x = torch.randn(1, 128, 12, 20)
+    x[0, 5, 6, 7] = 20000.0  # one activation above 65504 / 4
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    conv = ops.Conv2d(w, b, arithmetic="fp16x2")
+    assert conv.activation_range() == 16376.0
+    y = conv(x.to(DEV)).cpu()
+    touched = torch.zeros_like(ref, dtype=torch.bool)
+    touched[:, :, 5:8, 6:9] = True  # the 3x3 outputs that read the pixel
+    assert not torch.isfinite(y[touched]).any(), "an overflowing activation must poison every output that reads it"
+    assert torch.allclose(y[~touched], ref[~touched], atol=2e-5)
+    conv.calibrate(x.to(DEV))  # M = 20000 -> valid up to 65504 / 2^-4 = 1.05e6
+    assert 32 * 20000.0 <= 2 * conv.activation_range() and conv.activation_range() >= 20000.0 * 16
+    y = conv(x.to(DEV)).cpu()
+    assert torch.isfinite(y).all() and (y - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert torch.isfinite(conv((x * 16).to(DEV))).all()
+    y64 = conv((x * 64).to(DEV)).cpu()
+    assert not torch.isfinite(y64[touched]).any()
+
+
+@pytest.mark.parametrize("k", [-12, -6, 0, 6, 12], ids=lambda k: f"2^{k}")
+@pytest.mark.parametrize("arith", ARITHS)
+def test_update_block_over_input_scales(gold, arith, k):
+    """One update-block golden (RAFT-Stereo base: hidden 128, context 64) with its four inputs scaled by 2^k: the split arithmetic
+    (fp16x2 calibrated on the scaled inputs) against the float64 evaluation of the reference's update block on the same inputs,
+    relative to each output's scale, at the level of the exact fp32-MFMA path."""
+    from oracle import torch_ref as R
+    from nndepth_amd import ops, weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    name = "raft_h128_c64"
+    hid, ctx, cp, fc, sps = CASES[name]
+    g = gold("update_block.npz")
+    pre = "ub." + name
+    sd = weightgen.fill_state_dict(R.update_block_spec(pre, hid, cp, ctx, fc, sps))
+    ins = [t(g[f"{name}_{kk}"]) * 2.0 ** k for kk in ("net", "inp", "corr", "flow")]
+    truth = R.update_block({kk: v.double() for kk, v in sd.items()}, pre, *(i.double() for i in ins))
+    outs = {}
+    for a in ("fp32", arith):
+        ub = BasicUpdateBlock(hidden_dim=hid, cor_planes=cp, context_dim=ctx, flow_channel=fc, spatial_scale=sps, arithmetic=a)
+        ub.load_state_dict({kk[len(pre) + 1:]: v for kk, v in sd.items()})
+        ub = ub.to(DEV)
+        dev_ins = [i.to(DEV) for i in ins]
+        if a == "fp16x2":
+            with ops.calibration() as c:
+                ub(*dev_ins)
+            assert not (c.status & 1)
+        outs[a] = [o.cpu().double() for o in ub(*dev_ins)]
+    for j, key in enumerate(("net_out", "mask_out", "delta_out")):
+        sc = max(truth[j].abs().max().item(), 1e-30)
+        e32 = (outs["fp32"][j] - truth[j]).abs().max().item()
+        esp = (outs[arith][j] - truth[j]).abs().max().item()
+        print(f"\n[update block x 2^{k}] {key}: |y| max {sc:.3g}   exact fp32 {e32 / sc:.2e}   {arith} {esp / sc:.2e}")
+        assert np.isfinite(esp) and esp <= 1.5 * e32 + 1e-6 * sc, (key, esp, e32, sc)
+
+
 @pytest.mark.parametrize("arith", ARITHS)
 def test_split_conv_never_reads_outside_the_image(arith):
     """Same poison-border check as the fp32 kernel's staging (test_conv_staging_never_reads_outside_the_image)."""
