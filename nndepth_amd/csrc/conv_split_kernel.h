@@ -97,12 +97,32 @@ struct SplitGeom {
     static constexpr int PS = split_pos_bytes(NS), ROWB = split_row_bytes(PCP, NS), PHB = PRP * ROWB, SUBB = NPH * PHB;
 };
 
+// Schedule of the PIPELINED walk (round 4, FAST regime, kernels with >= 5 taps): the staging of super-chunk K + 1 is cut into
+// micro-steps — NU * 4 conversions of one (unit, channel pair) each and NU LDS writes — that hang behind the MFMA groups of the
+// units [U0, NUNIT - 2] of super-chunk K, SPU per unit; UL = the unit behind whose MFMAs the global loads of K + 1 are issued.
+__host__ __device__ constexpr int split_pipe_spu(int nunit, int nsteps, int ul) {
+    int v = 1;
+    while (v < nsteps && nunit - 1 - (nsteps + v - 1) / v < ul + 3) ++v;
+    return v;
+}
+template <int NT, int P, int NU>
+struct SplitPipe {
+    static constexpr int NUNIT = NT * P, NSTEPS = NU * 5, UL = 1;
+    static constexpr int SPU = split_pipe_spu(NUNIT, NSTEPS, UL), U0 = NUNIT - 1 - (NSTEPS + SPU - 1) / SPU;
+    static constexpr bool ON = NT >= 5 && P == 2;  // NUNIT even: the B-fragment slot rotation continues across super-chunks
+};
+
 template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD_, int MAXT, int STR = 1>
 __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     static_assert(STR == 1 || (FAST && !SRC4 && (KH * KW == 9 || KH * KW == 1)), "stride 2: 3x3 / 1x1, FAST regime, planar sources");
     using Geo = SplitGeom<KH, KW, NS, STR>;
     constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
     constexpr int PC = Geo::PCI, NPOS = Geo::NPOS;
+#ifndef NND_SPLIT_NO_PIPE
+    constexpr bool PIPE = FAST && SplitPipe<NT, P, NU>::ON;  // the pipelined walk below (round 4)
+#else
+    constexpr bool PIPE = false;
+#endif
     constexpr int PS = Geo::PS, ROWB = Geo::ROWB, SUBB = Geo::SUBB, PHB = Geo::PHB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     NND_SSTAMP(0);
@@ -142,7 +162,9 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     bool inimg[NU], own[NU];
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-        const int u = tid + i * nthreads;
+        // PIPE: a thread past the last unit repeats the last one (the same values to the same LDS address: harmless), so that the
+        // staging micro-steps are branch-free — behind an `own` test the compiler sinks all conversions down to the guarded LDS write
+        const int u = PIPE ? min(tid + i * nthreads, nunits - 1) : tid + i * nthreads;
         own[i] = u < nunits;
         const int pos = u % NPOS, rest = u / NPOS;
         const int pp = rest % P, oct = rest / P;
@@ -280,6 +302,96 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     NND_SSTAMP(1);
     NND_SCLOCK(5);
 
+    // ---- PIPELINED walk (round 4).  What the assembly of round 3's FAST loop showed at every super-chunk boundary: the global loads
+    // of the next patch were issued at the top of the chunk and the register allocator, short of registers, copied two of their
+    // destination registers right behind them (s_waitcnt vmcnt(2) directly after the issue: a full L2 round trip with every wave
+    // of the workgroup parked); the whole split of the next patch (about 90 VALU instructions per wave) ran behind the last MFMA
+    // of the chunk with all 12 waves in lock step, the matrix pipes idle; then the barrier, then the LDS latency of the first
+    // B fragments.  Now a super-chunk has no seam: the B fragment of the next unit — also across the chunk boundary — is always
+    // read one unit ahead; the next patch's loads are issued behind the MFMAs of unit UL; its split runs as micro-steps behind
+    // the MFMA groups of units U0 .. NUNIT-2 (the VALU port is free for ~3/4 of an MFMA's 32 cycles); and the barrier sits
+    // between the last two units: every LDS read of the current buffer and every write of the other one has been issued (and,
+    // by the barrier's lgkmcnt(0), completed) by then, while each wave still has a unit of MFMAs to issue behind it.
+    // Same values in the same order into the same accumulators as the walk below: bit-identical results.
+    uint4 bq2[2][NS];
+    uint32_t pw[NU][NS][4];
+    auto read_b2 = [&](const unsigned char* xb, int u, uint4 (&dst)[NS]) {
+        const int t = u / P, pp = u % P;
+        const int dy = t / KW, dx = t % KW;
+        const int toff = STR == 1 ? dy * ROWB + dx * PS : ((dy & 1) * 2 + (dx & 1)) * PHB + (dy >> 1) * ROWB + (dx >> 1) * PS;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + toff + s * 32);
+    };
+    auto micro = [&](int m, unsigned char* wbuf) {  // m: compile-time after unrolling
+        using PP = SplitPipe<NT, P, NU>;
+        if (m >= PP::NSTEPS) return;
+        if (m < NU * 4) {
+            const int i = m / 4, pr = m % 4;
+            float r0 = inimg[i] ? stage[i][2 * pr] : 0.f, r1 = inimg[i] ? stage[i][2 * pr + 1] : 0.f;
+            if constexpr (NS == 2) {
+                r0 *= xscale;
+                r1 *= xscale;
+            }
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp) {
+                if constexpr (NS == 3) {
+                    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+                    v2 v;
+                    v[0] = (__bf16)r0; v[1] = (__bf16)r1;
+                    r0 -= (float)v[0]; r1 -= (float)v[1];
+                    pw[i][sp][pr] = __builtin_bit_cast(uint32_t, v);
+                } else {
+                    typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+                    v2 v;
+                    v[0] = (_Float16)r0; v[1] = (_Float16)r1;
+                    r0 -= (float)v[0]; r1 -= (float)v[1];
+                    pw[i][sp][pr] = __builtin_bit_cast(uint32_t, v);
+                }
+            }
+        } else {
+            const int i = m - NU * 4;  // every thread owns its units here (see `own`)
+#pragma unroll
+            for (int sp = 0; sp < NS; ++sp)
+                *reinterpret_cast<uint4*>(wbuf + loff[i] + sp * 32) = make_uint4(pw[i][sp][0], pw[i][sp][1], pw[i][sp][2], pw[i][sp][3]);
+        }
+    };
+    auto chunk_pipe = [&](int K, auto par_c, auto more_c) {
+        using PP = SplitPipe<NT, P, NU>;
+        constexpr int par = decltype(par_c)::value;
+        constexpr bool more = decltype(more_c)::value;
+        constexpr int NUNIT = PP::NUNIT;
+        const int BUFB = ks * P * SUBB;
+        const uint4* wc = a_ptr(K);
+        const uint4* wn = a_ptr(more ? K + 1 : K);  // past the end: re-reads the last chunk, never used
+        const unsigned char* xb = lds_raw + (K & 1) * BUFB + lane_base;
+        const unsigned char* xbn = lds_raw + ((K + 1) & 1) * BUFB + lane_base;
+        unsigned char* wbuf = lds_raw + ((K + 1) & 1) * BUFB;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint4(&ac)[NS] = abuf[(par + t) % NA];
+            uint4(&an)[NS] = abuf[(par + t + AD) % NA];
+            if (t + AD < NT) load_a(an, wc, t + AD);
+            else load_a(an, wn, t + AD - NT);
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                const int u = t * P + pp;
+                if (u + 1 < NUNIT) read_b2(xb, u + 1, bq2[(u + 1) & 1]);
+                else if (more) read_b2(xbn, 0, bq2[0]);  // unit 0 of the next super-chunk (the barrier below has passed)
+                __builtin_amdgcn_sched_barrier(0);
+                split_mfma_step<NS>(ac, bq2[u & 1], acc[pp]);
+                if (more) {
+                    if (u == PP::UL) load_x(K + 1);
+                    if (u >= PP::U0 && u <= NUNIT - 2) {
+#pragma unroll
+                        for (int q = 0; q < PP::SPU; ++q) micro((u - PP::U0) * PP::SPU + q, wbuf);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u == NUNIT - 2) __syncthreads();
+            }
+        }
+    };
+
     // `mine_c`: this wave's K slice exists in super-chunk K (always, in the FAST regime)
     auto chunk_body = [&](int K, auto par_c, auto mine_c) {
         constexpr int par = decltype(par_c)::value;
@@ -351,11 +463,25 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     };
     // the ring phase of a chunk's first step, (K*NT) % NA, must be a compile-time constant: walk the chunks in periods
     constexpr int STEP = NT % NA, PERIOD = NA / split_gcd(STEP, NA);
-    for (int K0 = 0; K0 < nsuper; K0 += PERIOD)
+    if constexpr (PIPE) read_b2(lds_raw + lane_base, 0, bq2[0]);  // unit 0 of super-chunk 0 (behind the prologue's barrier)
+    if constexpr (PIPE) {  // all super-chunks but the last stage their successor; the last one is its own code copy (no runtime test inside a chunk)
+        const int last = nsuper - 1;
+        for (int K0 = 0; K0 < last; K0 += PERIOD)
+            split_static_for<PERIOD>([&](auto j) {
+                constexpr int jj = decltype(j)::value;
+                if (jj == 0 || K0 + jj < last) chunk_pipe(K0 + jj, std::integral_constant<int, (jj * STEP) % NA>{}, std::true_type{});
+            });
         split_static_for<PERIOD>([&](auto j) {
             constexpr int jj = decltype(j)::value;
-            if (jj == 0 || K0 + jj < nsuper) chunk(K0 + jj, std::integral_constant<int, (jj * STEP) % NA>{});
+            if (PERIOD == 1 || last % PERIOD == jj) chunk_pipe(last, std::integral_constant<int, (jj * STEP) % NA>{}, std::false_type{});
         });
+    } else {
+        for (int K0 = 0; K0 < nsuper; K0 += PERIOD)
+            split_static_for<PERIOD>([&](auto j) {
+                constexpr int jj = decltype(j)::value;
+                if (jj == 0 || K0 + jj < nsuper) chunk(K0 + jj, std::integral_constant<int, (jj * STEP) % NA>{});
+            });
+    }
 
     NND_SSTAMP(2);
     NND_SCLOCK(6);

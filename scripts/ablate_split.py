@@ -46,7 +46,7 @@ for i, nm in enumerate(names):
 ''' % ROOT
 
 if __name__ == "__main__":
-    libs = [("product", None)] + [(n[4:-3], os.path.join(ROOT, "scripts/ablate", n)) for n in sorted(os.listdir(os.path.join(ROOT, "scripts/ablate")))]
+    libs = [("product", None)] + [(n[4:-3], os.path.join(ROOT, "scripts/ablate", n)) for n in sorted(os.listdir(os.path.join(ROOT, "scripts/ablate"))) if n.startswith("lib_") and n.endswith(".so")]
     for name, path in libs:
         env = dict(os.environ)
         if path:

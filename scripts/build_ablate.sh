@@ -8,7 +8,7 @@ make -j8 >/dev/null
 mkdir -p ../../scripts/ablate
 NS=${AB_NS:-2}
 OTHER_NS=$((5 - NS))
-OTHERS="conv_mfma.o conv_split_ns${OTHER_NS}.o corr1d.o agcl.o mask_upsample.o update_block.o encoder.o prepost.o cascade.o loftr.o conv3d.o thin3d.o slab3d.o error.o"
+OTHERS="conv_mfma.o conv_split_ns${OTHER_NS}.o corr1d.o agcl.o mask_upsample.o update_block.o encoder.o prepost.o cascade.o loftr.o conv3d.o thin3d.o slab3d.o calib.o error.o"
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize $flags -c conv_split.hip -o /tmp/cs_$name.o &&
