@@ -98,8 +98,10 @@ struct SplitGeom {
 };
 
 // Schedule of the PIPELINED walk (round 4, FAST regime, kernels with >= 5 taps): the staging of super-chunk K + 1 is cut into
-// micro-steps — NU * 4 conversions of one (unit, channel pair) each and NU LDS writes — that hang behind the MFMA groups of the
-// units [U0, NUNIT - 2] of super-chunk K, SPU per unit; UL = the unit behind whose MFMAs the global loads of K + 1 are issued.
+// micro-step slots that hang behind the MFMA groups of the units [U0, NUNIT - 2] of super-chunk K, SPU slots per unit; slot q
+// converts one (unit, channel pair) — q < 4 NU — and stores one 16-byte piece of the unit converted four slots earlier (one
+// ds_write_b128 per slot: 13 cycles of the CU's store path each, so a workgroup's 48 stores never pile up in front of the
+// barrier); UL = the unit behind whose MFMAs the global loads of K + 1 are issued.
 __host__ __device__ constexpr int split_pipe_spu(int nunit, int nsteps, int ul) {
     int v = 1;
     while (v < nsteps && nunit - 1 - (nsteps + v - 1) / v < ul + 3) ++v;
@@ -107,7 +109,7 @@ __host__ __device__ constexpr int split_pipe_spu(int nunit, int nsteps, int ul) 
 }
 template <int NT, int P, int NU>
 struct SplitPipe {
-    static constexpr int NUNIT = NT * P, NSTEPS = NU * 5, UL = 1;
+    static constexpr int NUNIT = NT * P, NSTEPS = NU * 4 + 3, UL = 1;  // slots: the last unit's pieces (<= 3) follow its conversions
     static constexpr int SPU = split_pipe_spu(NUNIT, NSTEPS, UL), U0 = NUNIT - 1 - (NSTEPS + SPU - 1) / SPU;
     static constexpr bool ON = NT >= 5 && P == 2;  // NUNIT even: the B-fragment slot rotation continues across super-chunks
 };
@@ -322,37 +324,46 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) dst[s] = *reinterpret_cast<const uint4*>(xb + pp * SUBB + toff + s * 32);
     };
-    auto micro = [&](int m, unsigned char* wbuf) {  // m: compile-time after unrolling
+    auto micro = [&](int q, unsigned char* wbuf) {  // slot q: compile-time after unrolling
         using PP = SplitPipe<NT, P, NU>;
-        if (m >= PP::NSTEPS) return;
-        if (m < NU * 4) {
-            const int i = m / 4, pr = m % 4;
-            float r0 = inimg[i] ? stage[i][2 * pr] : 0.f, r1 = inimg[i] ? stage[i][2 * pr + 1] : 0.f;
+        if (q >= PP::NSTEPS) return;
+        if (q < NU * 4) {
+            const int i = q / 4, pr = q % 4;
             if constexpr (NS == 2) {
-                r0 *= xscale;
-                r1 *= xscale;
-            }
+                // 4 instructions per channel pair: hi = rn_f16(s * x) for both channels into the two halves of one register, then
+                // lo = rn_f16(s * x - hi) reading hi's halves as the fp16 addend (v_fma_mix*: fp32 FMA with fp16 operands / result;
+                // s * x and s * x - hi are exact in fp32, so each piece is rounded once — the values of split_pieces_n).  The
+                // compiler's own selection for the C++ form below took 9 (it formed every hi piece twice).  Positions outside the
+                // image are zeroed through the scale (the clamped load returned a finite value), no per-element select.
+                const float sc = inimg[i] ? xscale : 0.f;
+                uint32_t hi, lo;
+                asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\t"
+                    "v_fma_mixhi_f16 %0, %2, %4, 0\n\t"
+                    "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixhi_f16 %1, %2, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                    : "=&v"(hi), "=&v"(lo)
+                    : "v"(sc), "v"(stage[i][2 * pr]), "v"(stage[i][2 * pr + 1]));
+                pw[i][0][pr] = hi;
+                pw[i][1][pr] = lo;
+            } else {
+                float r0 = inimg[i] ? stage[i][2 * pr] : 0.f, r1 = inimg[i] ? stage[i][2 * pr + 1] : 0.f;
 #pragma unroll
-            for (int sp = 0; sp < NS; ++sp) {
-                if constexpr (NS == 3) {
+                for (int sp = 0; sp < NS; ++sp) {
                     typedef __bf16 v2 __attribute__((ext_vector_type(2)));
                     v2 v;
                     v[0] = (__bf16)r0; v[1] = (__bf16)r1;
                     r0 -= (float)v[0]; r1 -= (float)v[1];
                     pw[i][sp][pr] = __builtin_bit_cast(uint32_t, v);
-                } else {
-                    typedef _Float16 v2 __attribute__((ext_vector_type(2)));
-                    v2 v;
-                    v[0] = (_Float16)r0; v[1] = (_Float16)r1;
-                    r0 -= (float)v[0]; r1 -= (float)v[1];
-                    pw[i][sp][pr] = __builtin_bit_cast(uint32_t, v);
                 }
             }
-        } else {
-            const int i = m - NU * 4;  // every thread owns its units here (see `own`)
-#pragma unroll
-            for (int sp = 0; sp < NS; ++sp)
-                *reinterpret_cast<uint4*>(wbuf + loff[i] + sp * 32) = make_uint4(pw[i][sp][0], pw[i][sp][1], pw[i][sp][2], pw[i][sp][3]);
+        }
+        const int w = q - 4;  // piece w % 4 of unit w / 4: its conversions ended with slot 4 * (w / 4) + 3 (every thread owns its units here, see `own`)
+        if (w >= 0 && w / 4 < NU && w % 4 < NS) {
+#ifdef NND_SPLIT_NO_LDSW
+            if (pw[w / 4][0][0] == 0x12345678u)
+#endif
+            *reinterpret_cast<uint4*>(wbuf + loff[w / 4] + (w % 4) * 32) =
+                make_uint4(pw[w / 4][w % 4][0], pw[w / 4][w % 4][1], pw[w / 4][w % 4][2], pw[w / 4][w % 4][3]);
         }
     };
     auto chunk_pipe = [&](int K, auto par_c, auto more_c) {
@@ -370,22 +381,38 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
         for (int t = 0; t < NT; ++t) {
             uint4(&ac)[NS] = abuf[(par + t) % NA];
             uint4(&an)[NS] = abuf[(par + t + AD) % NA];
+#ifndef NND_SPLIT_NO_ALOAD  // (timing-only ablation builds: scripts/build_ablate.sh)
             if (t + AD < NT) load_a(an, wc, t + AD);
             else load_a(an, wn, t + AD - NT);
+#else
+            for (int s = 0; s < NS; ++s) an[s] = ac[s];
+#endif
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 const int u = t * P + pp;
+#ifndef NND_SPLIT_NO_BREAD
                 if (u + 1 < NUNIT) read_b2(xb, u + 1, bq2[(u + 1) & 1]);
                 else if (more) read_b2(xbn, 0, bq2[0]);  // unit 0 of the next super-chunk (the barrier below has passed)
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef NND_SPLIT_NO_MFMA
                 split_mfma_step<NS>(ac, bq2[u & 1], acc[pp]);
+#else
+                if (acc[0][0] == 123.f) split_mfma_step<NS>(ac, bq2[u & 1], acc[pp]);
+#endif
+#ifndef NND_SPLIT_NO_STAGE
                 if (more) {
+#ifndef NND_SPLIT_NO_XLOAD
                     if (u == PP::UL) load_x(K + 1);
+#endif
+#ifndef NND_SPLIT_NO_MICRO
                     if (u >= PP::U0 && u <= NUNIT - 2) {
 #pragma unroll
                         for (int q = 0; q < PP::SPU; ++q) micro((u - PP::U0) * PP::SPU + q, wbuf);
                     }
+#endif
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (u == NUNIT - 2) __syncthreads();
             }
