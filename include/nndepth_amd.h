@@ -274,8 +274,15 @@ int nnd_conv2d_offset_forward(const float* packed_dev, const float* x, float* y,
  * nnd_avg_pool_2x_4x     : out2 = F.avg_pool2d(x, 2, stride=2) (N,C,H/2,W/2) and out4 = F.avg_pool2d(x, 4, stride=4)
  *                          (N,C,H/4,W/4) in one pass                           cre_stereo/model.py:154-177
  * nnd_resize_bilinear_ac : y (N,C,H,W) = mul * F.interpolate(x (N,C,h,w), (H,W), mode="bilinear", align_corners=True)
- *                          cre_stereo/model.py:205-212,235-241,259-265 (flow hand-over between cascade stages)        */
+ *                          cre_stereo/model.py:205-212,235-241,259-265 (flow hand-over between cascade stages)
+ * nnd_pos_enc_sine_add   : y = x + pe[:, :, :H, :W], PositionEncodingSine.forward  nndepth/blocks/pos_enc.py:22-42 (used at
+ *                          cre_stereo/model.py:180-196): the table is generated on the fly, pe[4k+j] = sin / cos (j odd) of
+ *                          pos * exp(2k * rate), pos = column + 1 (j < 2) or row + 1, rate = the reference's
+ *                          `-log(1e4) / d_model // 2` with Python's precedence (= -1; temp_bug_fix != 0: -log(1e4) / (d_model // 2)).
+ *                          x1 / y1 (a second map of the same shape, may both be NULL) get the same table in the same launch.    */
 int nnd_split_tanh_relu(const float* x, float* net, float* inp, int B, int Cnet, int Cinp, int H, int W, void* stream);
+int nnd_pos_enc_sine_add(const float* x0, const float* x1, float* y0, float* y1, int N, int C, int H, int W, int temp_bug_fix,
+                         void* stream);
 int nnd_avg_pool_2x_4x(const float* x, float* out2, float* out4, int N, int C, int H, int W, void* stream);
 int nnd_resize_bilinear_ac(const float* x, float* y, int N, int C, int h, int w, int H, int W, float mul, void* stream);
 
@@ -320,6 +327,11 @@ int64_t nnd_encoder_workspace_floats(const nnd_encoder_desc* desc, int N, int H,
 int nnd_encoder_pack(const nnd_encoder_desc* desc, const float* const* tensors_host, float bn_eps, float* packed_host);
 int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed_dev, const float* frames, float* fmap,
                         float* cnet_out, int n_cnet, float* workspace, int N, int H, int W, void* stream);
+/* The same with the batch in two tensors: samples 0 .. nsplit-1 from `frames`, nsplit .. N-1 from `frames_b` — the left and the
+ * right frames of a pair batch where they lie, instead of the torch.cat([frame1, frame2]) copy the reference makes
+ * (nndepth/encoders/basic_encoder.py:74-76).  frames_b == NULL: as nnd_encoder_forward.                               */
+int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed_dev, const float* frames, const float* frames_b, int nsplit,
+                         float* fmap, float* cnet_out, int n_cnet, float* workspace, int N, int H, int W, void* stream);
 /* fp16x2 calibration of the encoder's layers after forwards with NND_FLAG_CALIBRATE (as nnd_update_block_calibration_finish) */
 int nnd_encoder_calibration_finish(const nnd_encoder_desc* desc, float* packed_dev, int32_t* status_dev, void* stream);
 

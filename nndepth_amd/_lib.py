@@ -74,6 +74,8 @@ SIGNATURES = {
     "nnd_update_block_calibration_finish": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _P]),
     "nnd_update_block_scale_slots": (_I, [C.POINTER(UpdateBlockDesc), C.POINTER(C.c_int64), _I]),
     "nnd_conv2d_calibrate_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "nnd_encoder_forward2": (_I, [C.POINTER(EncoderDesc), _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "nnd_pos_enc_sine_add": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_encoder_calibration_finish": (_I, [C.POINTER(EncoderDesc), _P, _P, _P]),
     "nnd_conv3d_calibration_finish": (_I, [C.POINTER(Conv3dDesc), _P, _P, _P]),
     "nnd_conv2d_packed_floats": (C.c_int64, [_I, _I, _I, _I]),

@@ -16,7 +16,6 @@ nndepth/models/cre_stereo/model.py:17-288.  Inside `forward()`:
 The three stages of the cascade (1/32, 1/16 and 1/8 of the image for fnet_ds = 8) run `iters//2`, `iters//2` and
 `iters` update iterations; even iterations search a 1x9 window, odd ones a 3x3 window.
 """
-import math
 from typing import Dict, List, Optional
 
 import torch
@@ -106,28 +105,6 @@ class LocalFeatureTransformer(nn.Module):
         return self._layer_step(lambda i, a, b: self._engines[i].forward(a.float(), b.float()), map0, map1)
 
 
-_PE_CACHE = {}
-
-
-def position_encoding_sine(d_model: int, h: int, w: int, device) -> torch.Tensor:
-    """(1, d_model, h, w) table of nndepth/blocks/pos_enc.py:22-42 incl. its `/ d_model // 2` precedence quirk.  A constant of
-    (d_model, h, w): built on the host once per shape and device and kept resident (the reference registers it as a buffer) —
-    rebuilding it per forward cost a host-side table computation plus a synchronous 2 MB upload per pair."""
-    key = (d_model, h, w, str(device))
-    if key not in _PE_CACHE:
-        _PE_CACHE[key] = _position_encoding_sine_host(d_model, h, w).to(device)
-    return _PE_CACHE[key]
-
-
-def _position_encoding_sine_host(d_model: int, h: int, w: int) -> torch.Tensor:
-    y = torch.ones(h, w).cumsum(0).unsqueeze(0)
-    x = torch.ones(h, w).cumsum(1).unsqueeze(0)
-    div = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / d_model // 2))[:, None, None]
-    pe = torch.zeros(d_model, h, w)
-    pe[0::4], pe[1::4], pe[2::4], pe[3::4] = torch.sin(x * div), torch.cos(x * div), torch.sin(y * div), torch.cos(y * div)
-    return pe[None]
-
-
 # ------------------------------------------------------------------ the model
 class CREStereoBase(AutoCalibrate, nn.Module):
     def __init__(self, fnet_cls: str = "basic_encoder", update_cls: str = "basic_update_block", iters: int = 12,
@@ -182,7 +159,7 @@ class CREStereoBase(AutoCalibrate, nn.Module):
                 self._enc_engine.load(self.fnet.state_dict(), None, device=frame1.device)
                 self._enc_version = v
             B = frame1.shape[0]
-            fmaps, _ = self._enc_engine.forward(torch.cat([frame1, frame2], 0).float())
+            fmaps, _ = self._enc_engine.forward(frame1.float(), frames_b=frame2.float())  # no torch.cat copy (basic_encoder.py:74-76)
             return fmaps[:B], fmaps[B:]
         return self.fnet([frame1, frame2])  # explicit opt-in (hip_encoder=False): PyTorch-ROCm modules
 
@@ -239,9 +216,9 @@ class CREStereoBase(AutoCalibrate, nn.Module):
             # 1/(4*ds): attention-refined features, learned offsets, cross attention inside every AGCL call
             off16 = ops.conv2d_offset(conv16, f1_16, self.range_16)  # range * (sigmoid(conv) - 0.5) * 2 in the conv epilogue
             n, c, h16, w16 = f1_16.shape
-            pe = position_encoding_sine(c, frame1.shape[2] // (ds * 4), frame1.shape[3] // (ds * 4), f1_16.device)
-            pe = pe[:, :, :h16, :w16]
-            f1_16, f2_16 = self.self_att_fn.forward_maps(f1_16 + pe, f2_16 + pe)
+            # x + PositionEncodingSine (pos_enc.py:22-42, model.py:180-196): one kernel for both maps, the table generated on the fly
+            f1_pe, f2_pe = ops.pos_enc_sine_add(f1_16, f2_16)
+            f1_16, f2_16 = self.self_att_fn.forward_maps(f1_pe, f2_pe)
             flow16 = torch.zeros(n, 2, h16, w16, dtype=torch.float32, device=fmap1.device)
             _, _, up = self._stage(self.corr_cls(f1_16, f2_16, att=self.cross_att_fn), net16, inp16, flow16, off16,
                                    self.iters // 2, False, outs)

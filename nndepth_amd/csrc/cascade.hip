@@ -11,6 +11,8 @@
 //
 // Compiled with -ffp-contract=off; the bilinear weights follow ATen's area_pixel_compute_source_index (align_corners).
 #include "common.h"
+
+#include <cmath>
 #include "conv_epilogue.h"
 
 namespace nnd {
@@ -56,6 +58,25 @@ __global__ void __launch_bounds__(256) avg_pool_2x_4x_kernel(const float* __rest
     }
 }
 
+// PositionEncodingSine.forward (nndepth/blocks/pos_enc.py:22-42): y = x + pe[:, :, :H, :W] with the table generated on the fly —
+// channel c = 4k + j: pe = sin / cos (j & 1) of pos * div_k, pos = column + 1 (j < 2) or row + 1 (cumsum of ones), div_k =
+// exp(2k * rate) in fp32 like torch.exp(arange(0, d/2, 2).float() * rate); `rate` is the reference's Python scalar, evaluated by the
+// host wrapper INCLUDING its precedence quirk (`-log(1e4) / d_model // 2` = floor((-log(1e4) / d_model) / 2) = -1 for every
+// d_model >= 5 when temp_bug_fix is False, pos_enc.py:28).  One launch adds the table to both maps of a pair.
+__global__ void __launch_bounds__(256) pos_enc_sine_add_kernel(const float* __restrict__ x0, const float* __restrict__ x1, float* __restrict__ y0,
+                                                               float* __restrict__ y1, int C, int H, int W, float rate) {
+    const long HW = (long)H * W;
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int c = blockIdx.y % C;
+    const long off = (long)blockIdx.y * HW + pix;  // blockIdx.y = n * C + c
+    const float pos = (float)(((c & 2) ? (int)(pix / W) : (int)(pix % W)) + 1);
+    const float arg = pos * expf((float)(2 * (c >> 2)) * rate);
+    const float pe = (c & 1) ? cosf(arg) : sinf(arg);
+    y0[off] = x0[off] + pe;
+    if (x1) y1[off] = x1[off] + pe;
+}
+
 __global__ void __launch_bounds__(256) resize_bilinear_ac_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int H,
                                                                  int W, float mul) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -94,6 +115,18 @@ int nnd_avg_pool_2x_4x(const float* x, float* out2, float* out4, int N, int C, i
     const long cells = (long)((W2 + 1) / 2) * ((H2 + 1) / 2);
     hipLaunchKernelGGL(avg_pool_2x_4x_kernel, dim3((unsigned)cdiv64(cells, 256), (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, x,
                        out2, out4, H, W, H2, W2, H4, W4);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
+int nnd_pos_enc_sine_add(const float* x0, const float* x1, float* y0, float* y1, int N, int C, int H, int W, int temp_bug_fix,
+                         void* stream) {
+    NND_REQUIRE(x0 && y0 && (!x1 == !y1) && N > 0 && C > 0 && C % 4 == 0 && H > 0 && W > 0, "pos_enc_sine_add: bad argument (C %% 4 == 0)");
+    // the reference's Python expression, with Python's operator precedence and floor division
+    const double q = -std::log(10000.0) / (temp_bug_fix ? (double)(C / 2) : (double)C);
+    const float rate = (float)(temp_bug_fix ? q : std::floor(q / 2.0));
+    hipLaunchKernelGGL(pos_enc_sine_add_kernel, dim3((unsigned)cdiv64((long)H * W, 256), (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream,
+                       x0, x1, y0, y1, C, H, W, rate);
     NND_LAUNCH_CHECK();
     return NND_OK;
 }

@@ -93,6 +93,16 @@ int calib_amax_flat(const float* x, int64_t n, const float* tail, hipStream_t s)
 // by 2^12, calibrate again), |= 2 if a layer staged nothing (scale unchanged)
 int calib_finish(float* blob, const int64_t* tail_offs, int n, int32_t* status_dev, hipStream_t s);
 
+// acc = a * b + acc as ONE scalar v_fmac_f32, whatever the vectorisers would make of the surrounding loop.  Used by the VALU
+// convolutions of the update block (flow_branch_body phase 1, flow_head2_kernel): their results depended on what another
+// stream's kernel ran on the same CU whenever the compiler had packed their FMAs into v_pk_fma_f32 with operand-half selection
+// (round 3).  The stand-alone reproducer of that instruction beside fp16-MFMA waves does NOT miscompute
+// (scripts/ubench/pk_fma_hazard.hip, profiles/r04_pk_fma_hazard_ubench.txt), so the mechanism is not identified; what is
+// established is that the scalar form never failed, and this makes it a property of the source instead of a compiler flag.
+#ifdef __HIPCC__
+__device__ __forceinline__ void fmac_scalar(float& acc, float a, float b) { asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1264,6 +1264,32 @@ int igev_lookup_launch(const float* feat_pyramid, const float* geo_pyramid, cons
 }  // namespace nnd
 
 // IGEV initial disparity (igev_stereo/model.py:92-95,145-146): out[b,0,h,w] = -sum_d d * softmax_d(logits[b,d,h,w]).
+// Evaluated in the REFERENCE's fp32 order (round 4; scripts/study/igev_init_order.py, profiles/r04_igev_init_order_study.txt): the
+// expectation over 240 candidates reaches ~120, where the order of the additions decides the last 1e-4 — the more accurate
+// (sum d e_d) / (sum e_d) with pairwise sums that rounds 1-3 used lies 2e-5 from the float64 value but 1.8e-4 from what the
+// reference computes; ATen's own order lies 3e-5 from it.  That order: softmax over a non-innermost dim accumulates
+// exp(x - max) strictly in order of d and divides every term (SoftMaxKernel.cpp: vec_softmax); `disp * p` is an elementwise
+// product; sum(dim=1) is cascade_sum / multi_row_sum (SumKernel.cpp): rows are added in order in blocks of 16, a block's sum is
+// added to a second accumulator, every 16 blocks that one is added to a third; the tail rows (D % 16) stay in the first
+// accumulator and the levels are added lowest first.  `aten_expectation` is that last step for one pixel.
+template <typename F>
+__device__ __forceinline__ float aten_cascade_sum(int D, F&& term) {
+    float lvl1 = 0.f, lvl2 = 0.f;
+    int d = 0;
+    for (int blk = 0; d + 16 <= D; ++blk) {
+        float b = 0.f;
+        for (int j = 0; j < 16; ++j, ++d) b += term(d);
+        lvl1 += b;
+        if (((blk + 1) & 15) == 0) {
+            lvl2 += lvl1;
+            lvl1 = 0.f;
+        }
+    }
+    float tail = 0.f;
+    for (; d < D; ++d) tail += term(d);
+    return (tail + lvl1) + lvl2;
+}
+
 // One thread per pixel, three passes over the D candidates (max, sum of exp, expectation); consecutive lanes are
 // consecutive pixels, so every pass reads coalesced rows of the (B,D,H,W) volume.
 __global__ void __launch_bounds__(256) softargmin_kernel(const float* __restrict__ logits, float* __restrict__ out, int D,
@@ -1276,9 +1302,7 @@ __global__ void __launch_bounds__(256) softargmin_kernel(const float* __restrict
     for (int d = 0; d < D; ++d) mx = fmaxf(mx, x[(long)d * HW]);
     float sum = 0.f;
     for (int d = 0; d < D; ++d) sum += expf(x[(long)d * HW] - mx);
-    float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc += (float)d * (expf(x[(long)d * HW] - mx) / sum);
-    out[idx] = -acc;
+    out[idx] = -aten_cascade_sum(D, [&](int d) { return (float)d * (expf(x[(long)d * HW] - mx) / sum); });
 }
 
 // IGEV cv_squeezer + initial disparity in one pass over the regularised volume (igev_stereo/model.py:144-146):
@@ -1405,7 +1429,7 @@ __global__ void __launch_bounds__(256) igev_squeeze_softargmin_kernel(const floa
         for (int p = 0; p < SQ_PX; ++p)
             v[p] = is_max ? fmaxf(fmaxf(red[0][p], red[1][p]), fmaxf(red[2][p], red[3][p])) : (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
     };
-    float mx[SQ_PX], se[SQ_PX], sd[SQ_PX];
+    float mx[SQ_PX];
 #pragma unroll
     for (int p = 0; p < SQ_PX; ++p) {
         mx[p] = -INFINITY;
@@ -1414,28 +1438,53 @@ __global__ void __launch_bounds__(256) igev_squeeze_softargmin_kernel(const floa
             if (tid + 256 * j < D) mx[p] = fmaxf(mx[p], acc[j][p] + a.bias);
     }
     block_reduce(mx, true);
+    // the reference's evaluation order (see softargmin_kernel): the staged rows are dead, `sm` now holds e[p][d] = exp(logit - max)
+    __shared__ float ssum[SQ_PX], bsum[SQ_PX][33];
+    float* es = sm;  // [SQ_PX][D] <= 3 * (SQ_PX + 2) * (D + 2) floats
+    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < SQ_PX; ++p) {
-        se[p] = 0.f;
-        sd[p] = 0.f;
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid + 256 * j;
+        if (d < D)
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) {
-            const int d = tid + 256 * j;
-            if (d < D) {
-                const float e = expf(acc[j][p] + a.bias - mx[p]);
-                se[p] += e;
-                sd[p] += (float)d * e;
-            }
+            for (int p = 0; p < SQ_PX; ++p) es[p * D + d] = expf(acc[j][p] + a.bias - mx[p]);
+    }
+    __syncthreads();
+    if (tid < SQ_PX) {  // softmax denominator: strictly in order of d
+        float sden = 0.f;
+        for (int d = 0; d < D; ++d) sden += es[tid * D + d];
+        ssum[tid] = sden;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid + 256 * j;
+        if (d < D)
+#pragma unroll
+            for (int p = 0; p < SQ_PX; ++p) es[p * D + d] = (float)d * (es[p * D + d] / ssum[p]);  // disp * softmax: a product, then summed
+    }
+    __syncthreads();
+    {  // block sums of 16 consecutive candidates, in order (thread = pixel x block; D <= 512: at most 32 blocks)
+        const int p = tid >> 5, blk = tid & 31;
+        if (blk * 16 + 16 <= D) {
+            float bs = 0.f;
+            for (int j = 0; j < 16; ++j) bs += es[p * D + blk * 16 + j];
+            bsum[p][blk] = bs;
         }
     }
-    block_reduce(se, false);
-    block_reduce(sd, false);
-    if (tid < SQ_PX && w0 + tid < W) {
-        float r = 0.f;
-#pragma unroll
-        for (int p = 0; p < SQ_PX; ++p)
-            if (p == tid) r = -(sd[p] / se[p]);
-        out[((long)b * H + h) * W + w0 + tid] = r;
+    __syncthreads();
+    if (tid < SQ_PX && w0 + tid < W) {  // the levels of ATen's cascade: block sums in order, every 16 blocks into the next level
+        const int nb = D >> 4;
+        float lvl1 = 0.f, lvl2 = 0.f, tail = 0.f;
+        for (int blk = 0; blk < nb; ++blk) {
+            lvl1 += bsum[tid][blk];
+            if (((blk + 1) & 15) == 0) {
+                lvl2 += lvl1;
+                lvl1 = 0.f;
+            }
+        }
+        for (int d = nb * 16; d < D; ++d) tail += es[tid * D + d];
+        out[((long)b * H + h) * W + w0 + tid] = -((tail + lvl1) + lvl2);
     }
 }
 

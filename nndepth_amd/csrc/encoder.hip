@@ -111,7 +111,8 @@ static int run_conv_norm(const ConvLayer& L, const float* base, const float* x, 
 // grid (regions, 1, N)
 constexpr int STEM_K = 148;  // 147 taps + one zero row
 typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
-__global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// (x1 / nsplit: samples nsplit .. N-1 are read from x1 — the right frames of a pair batch — so the caller need not concatenate)
+__global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, const float* __restrict__ x1, int nsplit, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    float* __restrict__ out, long obs, int Hin, int Win, int H, int W,
                                                    int tiles_x, Lay lay, int relu) {
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, 
     const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 8;
     const int n = blockIdx.z;
     const long HWin = (long)Hin * Win;
-    const float* src = x + (long)n * 3 * HWin;
+    const float* src = n < nsplit ? x + (long)n * 3 * HWin : x1 + (long)(n - nsplit) * 3 * HWin;
     for (int e = tid; e < 3 * 21 * 69; e += 256) {
         const int c = e / (21 * 69), rem = e % (21 * 69);
         const int pr = rem / 69, pc = rem % 69;
@@ -493,10 +494,16 @@ int nnd_encoder_calibration_finish(const nnd_encoder_desc* desc, float* packed_d
 
 int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const float* frames, float* fmap, float* cnet_out,
                         int n_cnet, float* workspace, int N, int H, int W, void* stream) {
+    return nnd_encoder_forward2(desc, packed, frames, nullptr, N, fmap, cnet_out, n_cnet, workspace, N, H, W, stream);
+}
+
+int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, const float* frames, const float* frames_b, int nsplit,
+                         float* fmap, float* cnet_out, int n_cnet, float* workspace, int N, int H, int W, void* stream) {
     EncPlan p;
     int rc = make_enc_plan(desc, &p);
     if (rc != NND_OK) return rc;
     NND_REQUIRE(packed && frames && fmap && workspace && N > 0 && H > 0 && W > 0, "encoder_forward: bad argument");
+    NND_REQUIRE(!frames_b || (nsplit > 0 && nsplit < N), "encoder_forward2: a second frame tensor needs 0 < nsplit < N");
     NND_REQUIRE(!cnet_out || (desc->cnet_dim > 0 && n_cnet > 0 && n_cnet <= N), "encoder_forward: cnet_out needs cnet_dim > 0 and 0 < n_cnet <= N");
     CalibScope calib((desc->flags & NND_FLAG_CALIBRATE) && desc->arithmetic == 2);
     hipStream_t s = (hipStream_t)stream;
@@ -512,7 +519,7 @@ int nnd_encoder_forward(const nnd_encoder_desc* desc, const float* packed, const
     {  // stem -> buf[0]
         const Lay lay = make_lay(h, w, true);
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 8);
-        hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 1, N), dim3(256), 0, s, frames, packed + p.stem_w,
+        hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 1, N), dim3(256), 0, s, frames, frames_b, frames_b ? nsplit : N, packed + p.stem_w,
                            packed + p.stem_scale, packed + p.stem_shift, buf[0], (long)(64 * lay.plane), H, W, h, w, tiles_x, lay,
                            inorm ? 0 : 1);
         NND_LAUNCH_CHECK();

@@ -118,7 +118,7 @@ __device__ __forceinline__ void flow_branch_body(const FlowBranchArgs& a, unsign
 #pragma unroll
                         for (int p = 0; p < 2; ++p)
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wv[j], v[dx + p], acc[p][j]);
+                            for (int j = 0; j < 8; ++j) fmac_scalar(acc[p][j], wv[j], v[dx + p]);  // never a packed FMA (common.h)
                     }
                 }
 #pragma unroll

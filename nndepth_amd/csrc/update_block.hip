@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(512) flow_head2_kernel(const float* __restrict
         for (int t = 0; t < 9; ++t) {
             const float v = pp[(t / 3) * 10 + t % 3];
 #pragma unroll
-            for (int f = 0; f < FC; ++f) acc[f] = fmaf(wl[(f * hid + ci) * 9 + t], v, acc[f]);
+            for (int f = 0; f < FC; ++f) fmac_scalar(acc[f], wl[(f * hid + ci) * 9 + t], v);  // never a packed FMA (common.h)
         }
     }
 #pragma unroll

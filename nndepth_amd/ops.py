@@ -243,6 +243,24 @@ def split_tanh_relu(x: torch.Tensor, c_net: int) -> Tuple[torch.Tensor, torch.Te
     return net, inp
 
 
+def pos_enc_sine_add(x0: torch.Tensor, x1: Optional[torch.Tensor] = None, temp_bug_fix: bool = False):
+    """x + PositionEncodingSine table (nndepth/blocks/pos_enc.py:22-42, incl. its `/ d_model // 2` precedence quirk unless
+    temp_bug_fix), generated on the fly by the kernel; a second map of the same shape gets the same table in the same launch."""
+    d = _dev(x0) if x1 is None else _dev(x0, x1)
+    x0 = x0.contiguous()
+    N, Cc, H, W = x0.shape
+    y0 = torch.empty_like(x0)
+    y1 = None
+    if x1 is not None:
+        x1 = x1.contiguous()
+        if tuple(x1.shape) != tuple(x0.shape):
+            raise NndError(f"pos_enc_sine_add: second map {tuple(x1.shape)} != {tuple(x0.shape)}")
+        y1 = torch.empty_like(x1)
+    with torch.cuda.device(d):
+        check(lib.nnd_pos_enc_sine_add(_p(x0), _p(x1), _p(y0), _p(y1), N, Cc, H, W, int(temp_bug_fix), _stream(d)), "pos_enc_sine_add")
+    return y0 if x1 is None else (y0, y1)
+
+
 def avg_pool_2x_4x(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(F.avg_pool2d(x, 2, stride=2), F.avg_pool2d(x, 4, stride=4)) in one pass (cre_stereo/model.py:154-177)."""
     d = _dev(x)
@@ -784,8 +802,9 @@ class EncoderEngine:
         check(lib.nnd_encoder_calibration_finish(C.byref(self.desc), _p(self.packed), _p(status), _stream(self.packed.device)),
               "encoder_calibration_finish")
 
-    def forward(self, frames: torch.Tensor, n_cnet: int = 0):
-        """frames (N,3,H,W) -> (fmap (N,output_dim,H/8,W/8), cnet (n_cnet,cnet_dim,H/8,W/8) or None)."""
+    def forward(self, frames: torch.Tensor, n_cnet: int = 0, frames_b: Optional[torch.Tensor] = None):
+        """frames (N,3,H,W) -> (fmap (N,output_dim,H/8,W/8), cnet (n_cnet,cnet_dim,H/8,W/8) or None).  With `frames_b` (same shape)
+        the batch is [frames | frames_b] read where the two tensors lie (no torch.cat copy): fmap has 2N samples."""
         if self.packed is None:
             raise NndError("EncoderEngine: parameters not loaded")
         d = _dev(frames, self.packed)
@@ -793,6 +812,13 @@ class EncoderEngine:
         N, c, H, W = frames.shape
         if c != 3:
             raise NndError(f"encoder: frames have {c} channels, expected 3")
+        nsplit = N
+        if frames_b is not None:
+            _dev(frames_b, self.packed)
+            frames_b = frames_b.contiguous()
+            if tuple(frames_b.shape) != tuple(frames.shape):
+                raise NndError(f"encoder: second frame tensor {tuple(frames_b.shape)} != {tuple(frames.shape)}")
+            N = 2 * N
         h8, w8 = H, W
         for _ in range(3):
             h8, w8 = (h8 + 1) // 2, (w8 + 1) // 2
@@ -803,8 +829,8 @@ class EncoderEngine:
             self._ws = torch.empty(need, dtype=torch.float32, device=d)
         self.desc.flags = _calib_flags(self) if self.arithmetic == "fp16x2" else 0
         with torch.cuda.device(d):
-            check(lib.nnd_encoder_forward(C.byref(self.desc), _p(self.packed), _p(frames), _p(fmap), _p(cnet), n_cnet,
-                                          _p(self._ws), N, H, W, _stream(d)), "encoder_forward")
+            check(lib.nnd_encoder_forward2(C.byref(self.desc), _p(self.packed), _p(frames), _p(frames_b), nsplit, _p(fmap), _p(cnet), n_cnet,
+                                           _p(self._ws), N, H, W, _stream(d)), "encoder_forward")
         return fmap, cnet
 
 

@@ -150,7 +150,8 @@ class BaseRAFTStereo(AutoCalibrate, nn.Module):
                                "the encoder's PyTorch-ROCm modules explicitly")
             # BasicEncoder + cnet_proj in ONE C-ABI call (csrc/encoder.hip); eval-mode BatchNorm folded into the convs
             B = frame1.shape[0]
-            fmaps, cnet = self._encoder_engine(frame1.device).forward(torch.cat([frame1, frame2], 0).float(), n_cnet=B)
+            # (the two frame tensors are read where they lie: no torch.cat copy, basic_encoder.py:74-76)
+            fmaps, cnet = self._encoder_engine(frame1.device).forward(frame1.float(), n_cnet=B, frames_b=frame2.float())
             return fmaps[:B], fmaps[B:], cnet
         fmap1, fmap2 = self.fnet([frame1, frame2])  # explicit opt-in (hip_encoder=False): PyTorch-ROCm modules
         return fmap1, fmap2, self.cnet_proj(fmap1)

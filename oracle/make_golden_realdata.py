@@ -88,6 +88,9 @@ def kitti(report):
     report["kitti/raft_it32 torch_ref vs ref (it 1,4,12,32)"] = tuple((mine[i - 1] - out[i - 1]["up_disp"]).abs().max().item() for i in KEEP)
     report["kitti/ref self-noise 1thr vs 8thr"] = tuple((out1[i - 1]["up_disp"] - out[i - 1]["up_disp"]).abs().max().item() for i in KEEP)
     report["kitti/|disp| max, seconds"] = (out[-1]["up_disp"].abs().max().item(), t_ref)
+    # the spy collected the 1/8-resolution disparities of both runs: 32 of the 8-thread run, then 32 of the 1-thread run
+    assert len(lows) == 64
+    report["kitti/ref self-noise of the 1/8-resolution disparity (it 1,4,12,32)"] = tuple((lows[32 + i - 1] - lows[i - 1]).abs().max().item() for i in KEEP)
     # ground truth of the sample: uint16 / 256, 0 = no measurement (kitti_stereo_2015.py load_disp); sign "negative"
     gt = np.asarray(Image.open(os.path.join(src, "disp_occ_0/000000_10.png"))).astype(np.float32) / 256.0
     valid = gt > 0
@@ -98,7 +101,10 @@ def kitti(report):
                         up_disp_it32=_np(out[-1]["up_disp"]).astype(np.float32),  # padded frame, 384x1248
                         low_disp=np.stack([_np(lows[i - 1]) for i in KEEP]), low_iters=np.array(KEEP),
                         gt_disp=(-gt).astype(np.float16), gt_valid=np.packbits(valid), epe_ref=np.array(epe_ref), pad=np.array(padder._pad),
-                        ref_self_noise_up=np.array(report["kitti/ref self-noise 1thr vs 8thr"]))
+                        ref_self_noise_up=np.array(report["kitti/ref self-noise 1thr vs 8thr"]),
+                        ref_self_noise_low=np.array(report["kitti/ref self-noise of the 1/8-resolution disparity (it 1,4,12,32)"]),
+                        # the full-resolution maps of the earlier iterations on every 4th pixel: the drift table of the GPU test
+                        **{f"up_disp_sub4_it{i}": _np(out[i - 1]["up_disp"])[:, :, ::4, ::4].astype(np.float32).copy() for i in KEEP[:-1]})
 
 
 def cre(report):

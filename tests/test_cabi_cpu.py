@@ -269,12 +269,15 @@ def test_patch_swaps_the_seams_of_the_imported_reference_model(raft_sd):
 
 
 def test_no_packed_fp32_fma_in_the_update_blocks_valu_convolutions(tmp_path):
-    """Round-3 finding (profiles/r03_flow_branch_coresidency.txt): the packed-fp32 FMAs the SLP vectoriser formed in
-    the fused flow-branch kernel and in the 2-channel flow_head.conv2 kernel (v_pk_fma_f32 with a broadcast source half) returned
-    wrong values when another stream's fp16-MFMA waves shared the SIMD.  Those units are built with -fno-slp-vectorize; this test
-    disassembles the built library's gfx950 code objects and requires (i) the two kernels to be free of packed-fp32 arithmetic and
-    (ii) NO kernel of the library to hold the instruction with that signature — v_pk_fma_f32 with an `op_sel:[...]` modifier, i.e.
-    a register operand whose halves are swapped or broadcast (csrc/Makefile: the units where the vectoriser had formed it)."""
+    """Round-3 finding (profiles/r03_flow_branch_coresidency.txt): the fused flow-branch kernel and the 2-channel
+    flow_head.conv2 kernel returned wrong values when another stream's fp16-MFMA waves shared their CU, and only in builds in
+    which the compiler had packed their FMAs (v_pk_fma_f32 with a swapped / broadcast source half).  Round 4: the stand-alone
+    reproducer of that instruction pair does not miscompute (scripts/ubench/pk_fma_hazard.hip: 0 of 2 M results for every
+    half-selection form, victim and aggressor sharing the SIMDs), so the instruction itself is not the mechanism and the other
+    kernels of the library keep their packed code; the two kernels that did fail now issue their FMAs as explicit scalar
+    v_fmac_f32 (common.h: fmac_scalar) — a property of the source — and this test holds the built library to it:
+    (i) those kernels contain no packed-fp32 arithmetic at all; (ii) the half-selecting form — `op_sel:[...]` or an
+    `op_sel_hi` other than [1,1,1] (the round-3 regex missed the second) — is counted per kernel and must be absent from them."""
     import re
     import shutil
     import subprocess
@@ -288,6 +291,7 @@ def test_no_packed_fp32_fma_in_the_update_blocks_valu_convolutions(tmp_path):
     objs = [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]
     assert objs, "no gfx950 code object in the library"
     seen = set()
+    halfsel = {}
     for f in objs:
         dis = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
         for m in re.finditer(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
@@ -296,7 +300,11 @@ def test_no_packed_fp32_fma_in_the_update_blocks_valu_convolutions(tmp_path):
                 seen.add(name)
                 packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", body)
                 assert not packed, f"{name}: {len(packed)} packed-fp32 instructions"
-            bcast = re.findall(r"v_pk_fma_f32[^\n]* op_sel:\[", body)
-            assert not bcast, f"{name}: {len(bcast)} packed-fp32 FMAs with swapped / broadcast operand halves"
+            bcast = [ln for ln in re.findall(r"v_pk_fma_f32[^\n]*", body)
+                     if re.search(r"op_sel:\[", ln) or re.search(r"op_sel_hi:\[(?!1,1,1\])", ln)]
+            if bcast:
+                halfsel[name] = len(bcast)
+            assert not (bcast and ("flow_branch" in name or "flow_head2" in name)), f"{name}: {len(bcast)} half-selecting packed FMAs"
     assert any("flow_branch_kernel" in n for n in seen) and any("flow_head2_kernel" in n for n in seen) and \
         any("flow_branch_lookup_kernel" in n for n in seen), sorted(seen)
+    print("kernels with half-selecting v_pk_fma_f32 (accepted outside the update block's VALU convolutions):", halfsel)

@@ -27,8 +27,8 @@ def _u(tag, *shape, lo=-1.0, hi=1.0):
 
 
 # ------------------------------------------------------------------------------------------ config 3: IGEV 544x960
-@pytest.mark.parametrize("B", [1, 2])
-def test_igev_config3_136x240_vs_oracle(R, B):
+@pytest.mark.parametrize("B,iters", [(1, 32), (2, 8)], ids=["B1-32it", "B2-8it"])
+def test_igev_config3_136x240_vs_oracle(R, B, iters):
     """configs[2] per-sample shape: fmaps (B,128,136,240), guides at 1/8, 1/16, 1/32 -> group-wise volume -> HIP Conv3d
     regulariser -> pyramids -> fused squeezer + soft-argmin -> 8 iterations of the IGEV loop (hidden 64, 576 correlation
     channels, rate 4), every stage against the oracle (nndepth/models/igev_stereo/model.py:121-160, cost_volume.py:32-98).
@@ -37,7 +37,7 @@ def test_igev_config3_136x240_vs_oracle(R, B):
     from nndepth_amd.blocks import BasicUpdateBlock
     from nndepth_amd.cost_volume import GeometryAwareCostVolume
     from nndepth_amd.igev_stereo import CostVolumeFilterNetwork
-    C, G, H, W, iters = 128, 8, 136, 240, 8
+    C, G, H, W = 128, 8, 136, 240  # iters: BASELINE.json's 32 at batch 1 (round 4), 8 at batch 2
     # right map = left map shifted by a few pixels + noise, so the volume has a ridge and the soft-argmin a real peak
     f1 = _u(f"c3f1_{B}", B, C, H, W)
     f2 = torch.roll(f1, -7, dims=-1) + 0.1 * _u(f"c3f2_{B}", B, C, H, W)
@@ -97,7 +97,9 @@ def test_igev_config3_136x240_vs_oracle(R, B):
     e_init_e2e = (ops.igev_init_disparity(cv.geo_aware_cv[0], sq_w, sq_b, B, G, H, W, W).cpu() - init).abs().max().item()
     print(f"[config3 B={B}] init disparity {e_init:.2e} on the oracle's volume, {e_init_e2e:.2e} end to end "
           f"(range {init.min().item():.1f} .. {init.max().item():.1f})")
-    assert e_init <= 2e-5 * W and e_init_e2e <= 1e-3 * W
+    # (round 4: the kernel evaluates the soft-argmin in ATen's order, csrc/corr1d.hip; measured 4.7e-4 .. 5.4e-4 and 5.8e-4 .. 5.9e-4 on
+    #  disparities up to 127 whose x500 logits make exp() amplify one ulp of a logit to 3e-5 relative; bars = 1.5 x the measurement)
+    assert e_init <= 8e-4 and e_init_e2e <= 9e-4
     # a14 at full size: combined 576-channel lookup, bit-exact on identical pyramids
     coords = torch.arange(W).float()[None, None, None].repeat(B, 1, H, 1) + init
     got_lk = ops.igev_lookup(torch.cat([p.reshape(-1) for p in fp]).to(DEV), torch.cat([p.reshape(-1) for p in gp]).to(DEV),
@@ -199,23 +201,36 @@ def test_igev_config3_batch8_full_size_properties(R):
             e_low = (low1 - low8[k:k + 1]).abs().max().item()
             e_up = (up1[:, 0] - up8[:, k]).abs().max().item()
             print(f"[config3 batch 8 {ar}] sample {k} alone vs in the batch: init {e_init:.1e}, coordinates {e_low:.1e}, up_disp {e_up:.1e}")
-            assert e_init <= 1e-3 and e_low <= 2e-5 and e_up <= 5e-4
+            assert e_init == 0.0 and e_low <= 2e-5 and e_up <= 5e-4  # measured 0 / 1.5e-5 (one ulp) / 3.7e-4
             del cv1
     del cv8, il8
 
 
 # ------------------------------------------------------------------------------------------ config 4: KITTI batch 8
 def test_raft_config4_kitti_batch8_vs_oracle(raft_sd, R):
-    """configs[3] per-GPU work: 8 pairs of 375x1242 -> Padder(divis_by=32) -> 384x1248 -> RAFT-Stereo base, 4 iterations,
-    unpad; vs the oracle on the same frames (nndepth/data/dataloaders/utils.py:5-21, raft_stereo/model.py:111-139)."""
+    """configs[3] per-GPU work: 8 pairs of 375x1242 -> Padder(divis_by=32) -> 384x1248 -> RAFT-Stereo base, 32 iterations,
+    unpad; vs the oracle on the same frames (nndepth/data/dataloaders/utils.py:5-21, raft_stereo/model.py:111-139).
+    Bars: iterations 1 .. 12 are held to the north-star's 1e-4; over 32 iterations the recurrence amplifies rounding on such
+    frames until the oracle's OWN result depends on its thread count by about that much (the reference on the real KITTI pair:
+    9.6e-5 between 1 and 8 threads, tests/golden/REPORT_realdata.txt) — so the late iterations are held to 1e-4 plus the oracle's
+    self-noise measured here on sample 0 (the same forward on one thread), i.e. to staying inside the oracle's own envelope."""
     from nndepth_amd import weightgen
     from nndepth_amd.prepost import Padder
     from nndepth_amd.raft_stereo import BaseRAFTStereo
-    iters, Bn = 4, 8
+    iters, Bn = 32, 8  # BASELINE.json's iteration count (round 4; rounds 2-3 ran 4)
     f1, f2 = weightgen.synthetic_frames(11, Bn, 375, 1242)
     pads = R.padder_pads((375, 1242), 32)
     with torch.no_grad():
         ref = R.raft_stereo_forward(raft_sd, R.padder_pad(f1, pads), R.padder_pad(f2, pads), iters)
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            ref1 = R.raft_stereo_forward(raft_sd, R.padder_pad(f1[:1], pads), R.padder_pad(f2[:1], pads), iters)
+        finally:
+            torch.set_num_threads(nthr)
+    noise = [(a - b[:1]).abs().max().item() for a, b in zip(ref1, ref)]
+    print(f"\n[config4] oracle self-noise on sample 0 ({nthr} threads vs 1), iterations 1 / 4 / 12 / {iters}: "
+          f"{noise[0]:.2e} {noise[3]:.2e} {noise[11]:.2e} {noise[-1]:.2e}")
     padder = Padder((375, 1242), divis_by=32)
     p1, p2 = padder.pad(f1.to(DEV), f2.to(DEV))
     assert tuple(p1.shape) == (Bn, 3, 384, 1248)
@@ -227,31 +242,43 @@ def test_raft_config4_kitti_batch8_vs_oracle(raft_sd, R):
         got = [padder.unpad(o["up_disp"]).cpu() for o in out]
         assert tuple(got[-1].shape) == (Bn, 1, 375, 1242)
         errs = [(g - R.padder_unpad(r, pads)).abs().max().item() for g, r in zip(got, ref)]
-        print(f"\n[config4 {ar}] 8 x 375x1242, {iters} iterations, max-abs per iteration:", " ".join(f"{e:.2e}" for e in errs))
-        assert max(errs) <= 1e-4
+        print(f"\n[config4 {ar}] 8 x 375x1242, {iters} iterations, max-abs at iterations 1 / 4 / 12 / {iters}: "
+              f"{errs[0]:.2e} {errs[3]:.2e} {errs[11]:.2e} {errs[-1]:.2e} (largest {max(errs):.2e})")
+        assert max(errs[:12]) <= 1e-4 and all(e <= 1e-4 + n for e, n in zip(errs, noise))
         # per-sample independence at this size: sample 5 alone agrees with sample 5 of the batch.  Batch 1 and batch 8 pick other
         # workgroup shapes (split-K 4 vs 1: another summation order), so the two differ by rounding — each within ~3e-5 of the
         # oracle above — not bit for bit
         one = m(p1[5:6].contiguous(), p2[5:6].contiguous())[-1]["up_disp"]
-        assert (one[0] - out[-1]["up_disp"][5]).abs().max().item() <= 5e-5
+        e_one = (one[0] - out[-1]["up_disp"][5]).abs().max().item()
+        print(f"[config4 {ar}] sample 5 alone vs in the batch after {iters} iterations: {e_one:.2e}")
+        assert e_one <= 1e-4 + noise[-1]
 
 
 # ------------------------------------------------------------------------------------------ config 5: CREStereo 1080x1920
+ITERS5 = 20  # BASELINE.json configs[4]: 20 iterations (round 4; rounds 2-3 ran 2)
+
+
 def test_cre_config5_1080x1920_vs_oracle(cre_sd):
-    """configs[4] per-GPU work: one 1080x1920 pair through the 3-scale cascade (cre_stereo/model.py:131-288), iters = 2 ->
-    1 + 1 + 2 update steps, every output against the oracle."""
+    """configs[4] per-GPU work: one 1080x1920 pair through the 3-scale cascade (cre_stereo/model.py:131-288), iters = 20 ->
+    10 + 10 + 20 update steps, every output against the oracle (one CPU forward of the oracle: about a minute)."""
     from oracle import cre_ref as CR
     from nndepth_amd import weightgen
     from nndepth_amd.cre_stereo import CREStereoBase
     fr1, fr2 = weightgen.synthetic_frames(13, 1, 1080, 1920)
     with torch.no_grad():
-        exp = CR.cre_stereo_forward(cre_sd, fr1, fr2, 2)
+        exp = CR.cre_stereo_forward(cre_sd, fr1, fr2, ITERS5)
+    # Bar: the north-star's 1e-4 was stated for maps of |disparity| <= 25.8 (BASELINE.md §2), i.e. 3.9e-6 of the largest value; this
+    # pair's flow reaches 60 after 40 update steps, so the same relative precision is 1e-4 * |flow|max / 25.8
+    tol = 1e-4 * max(1.0, exp[-1].abs().max().item() / 25.8)
+    worst = {}
     for ar in ("fp32", "bf16x3", "fp16x2"):
-        m = CREStereoBase(iters=2, arithmetic=ar)
+        m = CREStereoBase(iters=ITERS5, arithmetic=ar)
         m.load_state_dict(cre_sd, strict=True)
         m = m.to(DEV).eval()
         outs = m(fr1.to(DEV), fr2.to(DEV))
-        assert len(outs) == len(exp) == 4 and tuple(outs[-1]["up_disp"].shape) == (1, 2, 1080, 1920)
+        assert len(outs) == len(exp) == 2 * ITERS5 and tuple(outs[-1]["up_disp"].shape) == (1, 2, 1080, 1920)
         errs = [(o["up_disp"].cpu() - e).abs().max().item() for o, e in zip(outs, exp)]
-        print(f"\n[config5 {ar}] 1080x1920 it2 max-abs per output:", " ".join(f"{e:.1e}" for e in errs), f"(|flow| max {exp[-1].abs().max():.1f})")
-        assert max(errs) <= 1e-4
+        print(f"\n[config5 {ar}] 1080x1920 it{ITERS5} max-abs per output:", " ".join(f"{e:.1e}" for e in errs[::4] + errs[-1:]), f"(every 4th + last; |flow| max {exp[-1].abs().max():.1f}, bar {tol:.2e})")
+        worst[ar] = max(errs)
+        del m, outs
+    assert max(worst.values()) <= tol, worst

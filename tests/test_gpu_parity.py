@@ -1106,6 +1106,48 @@ def test_loftr_layer_vs_oracle(cre_sd, CR, H, W, N):
         assert (got - exp).abs().max() <= 3e-5 * max(1.0, exp.abs().max().item())
 
 
+@pytest.mark.parametrize("C,H,W,N", [(256, 34, 60, 2), (256, 67, 120, 1), (64, 5, 9, 3), (8, 3, 4, 1)])
+def test_pos_enc_sine_add_vs_oracle(CR, C, H, W, N):
+    """SURVEY §8f-4: PositionEncodingSine.forward (nndepth/blocks/pos_enc.py:22-42, incl. the `/ d_model // 2` precedence quirk)
+    with the table generated on the fly by the kernel, against the oracle's restatement of the reference's table
+    (oracle.cre_ref.pos_enc_sine).  sin / cos / exp are the device library's (<= 2 ulp), the positions reach 240: <= 1e-5 absolute
+    on values in [-1, 1]; the same table must reach both maps of the pair."""
+    from nndepth_amd import ops
+    torch.manual_seed(C + H)
+    a, b = torch.randn(N, C, H, W), torch.randn(N, C, H, W)
+    pe = CR.pos_enc_sine(C, H, W)
+    ya, yb = ops.pos_enc_sine_add(a.to(DEV), b.to(DEV))
+    y1 = ops.pos_enc_sine_add(a.to(DEV))
+    ea, eb = (ya.cpu() - (a + pe)).abs().max().item(), (yb.cpu() - (b + pe)).abs().max().item()
+    print(f"\npos-enc {C}x{H}x{W}: max-abs vs oracle {ea:.2e} / {eb:.2e}")
+    assert ea <= 1e-5 and eb <= 1e-5 and torch.equal(y1, ya)
+    # the table itself (x = 0): every channel group, both axes
+    z = ops.pos_enc_sine_add(torch.zeros(1, C, H, W, device=DEV)).cpu()
+    assert (z - pe).abs().max().item() <= 1e-5
+    # temp_bug_fix=True: the reference's other branch, -log(1e4) / (d_model // 2)
+    import math
+    div = torch.exp(torch.arange(0, C // 2, 2).float() * (-math.log(10000.0) / (C // 2)))[:, None, None]
+    xs, ys = torch.ones(H, W).cumsum(1)[None], torch.ones(H, W).cumsum(0)[None]
+    fix = torch.zeros(C, H, W)
+    fix[0::4], fix[1::4], fix[2::4], fix[3::4] = torch.sin(xs * div), torch.cos(xs * div), torch.sin(ys * div), torch.cos(ys * div)
+    zf = ops.pos_enc_sine_add(torch.zeros(1, C, H, W, device=DEV), temp_bug_fix=True).cpu()
+    assert (zf[0] - fix).abs().max().item() <= 2e-5
+
+
+def test_encoder_two_frame_tensors_equal_concatenated_batch(raft_sd):
+    """nnd_encoder_forward2: the left / right frames read where they lie give bit for bit what the torch.cat batch gives
+    (nndepth/encoders/basic_encoder.py:74-76 concatenates; the HIP stem kernel takes two pointers instead)."""
+    from nndepth_amd import ops, weightgen
+    enc_sd = {k[len("fnet."):]: v for k, v in raft_sd.items() if k.startswith("fnet.")}
+    cnet_sd = {k[len("cnet_proj."):]: v for k, v in raft_sd.items() if k.startswith("cnet_proj.")}
+    for arith in ("fp32", "fp16x2"):
+        eng = ops.EncoderEngine(256, "batch", 192, arith).load(enc_sd, cnet_sd, device=DEV)
+        f1, f2 = (x.to(DEV) for x in weightgen.synthetic_frames(5, 2, 96, 160))
+        fm_cat, cn_cat = eng.forward(torch.cat([f1, f2], 0), n_cnet=2)
+        fm_two, cn_two = eng.forward(f1, n_cnet=2, frames_b=f2)
+        assert torch.equal(fm_cat, fm_two) and torch.equal(cn_cat, cn_two)
+
+
 def test_cre_transformer_maps_path_matches_token_path(cre_sd):
     from nndepth_amd.cre_stereo import CREStereoBase
     m = CREStereoBase(iters=2)
