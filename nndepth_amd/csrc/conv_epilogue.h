@@ -34,6 +34,7 @@ struct ConvArgs {
                                            // bit 2 LeakyReLU (negative slope = scale) after the affine
     const float* cscale;                   // EPI_AFFINE: per-channel scale (folded norm), shift comes in through `bias`
     float scale;
+    int dbg_stamp;                         // -DNND_DBG_STAMPS builds only: this launch records its phase stamps
 };
 
 // exp(x) to ~1 ulp without libm's special-case branches: x*log2(e) is split into the rounded product t and its

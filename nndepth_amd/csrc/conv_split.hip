@@ -196,7 +196,8 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     // tensors), planar tile-major (the encoder's) or NCHW (C-ABI tensors: cnet_proj reads the feature map, the Conv3d layers
     // their depth-major volumes); per candidate shape the picker also requires full super-chunks that never straddle the two
     // sources.  NND_SPLIT_NO_FAST (diagnostic) keeps the generic kernel.
-    const bool fast_ok = !switches().split_no_fast;
+    // (the stride-2 kernels exist in the FAST regime only: the diagnostic switch does not apply to them)
+    const bool fast_ok = !switches().split_no_fast || L.stride == 2;
     NND_REQUIRE(pick_split(L, io.src0.C, io.src1.C, B, H, W, fast_ok, &cfg), "conv_split: no configuration for %dx%d Cin=%d (%d+%d)", L.KH,
                 L.KW, L.Cin, io.src0.C, io.src1.C);
     ConvArgs a;
@@ -221,6 +222,14 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     NND_REQUIRE(epi != EPI_AFFINE || a.cscale, "conv_split: EPI_AFFINE needs a packed scale vector");
     a.tiles_x = cfg.tiles_x; a.wco = cfg.wco; a.ks = cfg.ks; a.npos = cfg.ntiles;
     a.scale = io.scale;
+#ifdef NND_DBG_STAMPS  // NND_DBG_STAMP_LAUNCH=n: only the n-th conv_split launch of the process records its stamps (default: every launch)
+    {
+        static std::atomic<int> launches{0};
+        static const int only = getenv("NND_DBG_STAMP_LAUNCH") ? atoi(getenv("NND_DBG_STAMP_LAUNCH")) : -1;
+        const int idx = launches.fetch_add(1);
+        a.dbg_stamp = only < 0 || idx == only;
+    }
+#endif
     if (calibrating() && L.arith == 2) {  // record the largest |activation| this launch stages (calib.hip)
         const float* tail = blob + L.tail_off();
         if (int rc = calib_amax_act(io.src0, a.ls, B, Hin, Win, tail, stream)) return rc;

@@ -42,7 +42,7 @@ namespace nnd {
 static __device__ unsigned long long g_split_stamps[4096 * 8];
 #define NND_SSTAMP(i)                                                                                  \
     do {                                                                                               \
-        if (threadIdx.x == 0) {                                                                        \
+        if (threadIdx.x == 0 && a.dbg_stamp) {                                                         \
             const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
             if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();        \
         }                                                                                              \
@@ -50,7 +50,7 @@ static __device__ unsigned long long g_split_stamps[4096 * 8];
 // shader-clock stamps (s_memtime) in slots 5 / 6 next to the real-time stamps 1 / 2: in-kernel clock of the K loop
 #define NND_SCLOCK(i)                                                                                  \
     do {                                                                                               \
-        if (threadIdx.x == 0) {                                                                        \
+        if (threadIdx.x == 0 && a.dbg_stamp) {                                                         \
             const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      \
             if (lin_ < 4096) g_split_stamps[lin_ * 8 + (i)] = __builtin_amdgcn_s_memtime();            \
         }                                                                                              \

@@ -283,6 +283,8 @@ __global__ void __launch_bounds__(256) in_apply_kernel(float* __restrict__ x, lo
 }
 
 static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, float eps, float* stats, double* partial, hipStream_t s) {
+    // in_partial_kernel reads 16 bytes per thread: a tile-major plane is a multiple of 32 floats, so only the base decides
+    NND_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && bs % 4 == 0, "encoder: instance-norm statistics need a 16-byte aligned workspace");
     hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, C, N), dim3(256), 0, s, x, (long)bs, C, H, W, make_lay(H, W, true), partial);
     NND_LAUNCH_CHECK();
     hipLaunchKernelGGL(in_final_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const double*)partial, N * C, H * W, eps, stats);
