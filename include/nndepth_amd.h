@@ -30,7 +30,8 @@
  *     Conv3d layers through the MFMA formulation instead of csrc/thin3d.hip), NND_NO_SLAB3D (the same layers at stride 1 with
  *     arithmetic = 2 through the round-2 formulations instead of the depth-marching MFMA kernel csrc/slab3d.hip),
  *     NND_SLAB3D_ROUNDS (depth segments of that kernel: grid of about this many resident sets), NND_NO_C4 (planar instead of 4-channel-
- *     interleaved layout of the update block's conv-only workspace tensors).
+ *     interleaved layout of the update block's conv-only workspace tensors), NND_ENC_NO_C4 (the same for the encoder's activations
+ *     with a split arithmetic).
  */
 #ifndef NNDEPTH_AMD_H
 #define NNDEPTH_AMD_H

@@ -50,6 +50,7 @@ struct Switches {
     bool lds_poison_on;               // NND_DEBUG_LDS_POISON=<pattern>: fill every CU's LDS with the pattern between the update block's launches
     unsigned lds_poison;
     int lds_slack;                    // NND_DEBUG_LDS_SLACK=<bytes>: conv_split launches ask for that much more dynamic LDS (diagnostic)
+    bool enc_no_c4;                   // NND_ENC_NO_C4: the encoder's activations planar tile-major also with a split arithmetic
     bool no_slab3d;                   // NND_NO_SLAB3D: thin Conv3d layers on the round-2 formulations (conv_split / thin3d)
     int slab3d_rounds;                // NND_SLAB3D_ROUNDS: depth segments so that the grid is about this many resident sets
 };

@@ -354,8 +354,26 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(ConvArgs a, int nti
         const bool pix_ok = y < a.H && x < a.W;
         const float* src = a.src0 + b * a.bs0 + (pix_ok ? pix_off(a.ls, y, x) : 0);  // tile-major: t*32 + l31, one line per channel
         float bv[NQ * 4];
+        if (a.ls.ci == 4) {
+            // 4 channels interleaved: the lower half-wave loads channel quad 2j of its pixel, the upper one quad 2j + 1 (one 16-B load
+            // per lane and 8 channels; every byte requested once).  The B operand of k pair (c, c + 1) wants channel c in the lower
+            // and c + 1 in the upper half: v_permlane32_swap exchanges the upper half of one register with the lower half of
+            // another — (a0|b0),(a1|b1) -> (a0|a1),(b0|b1) — so two swaps per 8 channels put every pair in place.  Same k order
+            // as the planar loads: bit-identical results.
 #pragma unroll
-        for (int kp = 0; kp < NQ * 4; ++kp) bv[kp] = src[(long)(2 * kp + h2) * SP];
+            for (int j = 0; j < NQ; ++j) {
+                const float4 q4 = *reinterpret_cast<const float4*>(src + (long)(2 * j + h2) * 4 * SP);
+                const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.x), __float_as_uint(q4.y), false, false);
+                const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.z), __float_as_uint(q4.w), false, false);
+                bv[4 * j + 0] = __uint_as_float(s01[0]);  // (a0 | a1): channels 8j, 8j+1
+                bv[4 * j + 1] = __uint_as_float(s23[0]);  // (a2 | a3)
+                bv[4 * j + 2] = __uint_as_float(s01[1]);  // (b0 | b1): channels 8j+4, 8j+5
+                bv[4 * j + 3] = __uint_as_float(s23[1]);  // (b2 | b3)
+            }
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < NQ * 4; ++kp) bv[kp] = src[(long)(2 * kp + h2) * SP];
+        }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -367,6 +385,36 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(ConvArgs a, int nti
         }
         if (!pix_ok) continue;
         const long pix = pix_off(a.ld, y, x);
+        if (a.ld.ci == 4) {  // registers 4q..4q+3 are 4 consecutive channels: one 16-B residual load / store per group (Cout % 4 == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co0 = cb * 32 + 8 * q + 4 * h2;
+                if (co0 >= a.Cout) continue;
+                float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (epi == EPI_AFFINE && a.aux0) r4 = *reinterpret_cast<const float4*>(a.aux0 + b * a.abs0 + (long)co0 * DP + pix);
+                const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int reg = 4 * q + i;
+                    float v;
+                    if (epi == EPI_AFFINE) {
+                        v = fmaf(acc[reg], sc_r[reg], bias_r[reg]);
+                        if (a.flags & 4) v = v > 0.f ? v : a.scale * v;
+                        if (a.flags & 1) v = fmaxf(v, 0.f);
+                        if (a.aux0) v = rr[i] + v;
+                        if (a.flags & 2) v = fmaxf(v, 0.f);
+                    } else {
+                        v = acc[reg] + bias_r[reg];
+                        if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+                        else if (epi == EPI_SCALE) v = a.scale * v;
+                    }
+                    o[i] = v;
+                }
+                *reinterpret_cast<float4*>(a.out0 + b * a.obs0 + (long)co0 * DP + pix) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            continue;
+        }
         float res[16];
         if (epi == EPI_AFFINE && a.aux0) {
 #pragma unroll
@@ -530,6 +578,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.ld = make_lay(H, W, io.dst_tiled, io.dst_c4);
     NND_REQUIRE(!io.src_c4 || (io.src_tiled && L.stride == 1 && io.src0.C % 4 == 0 && io.src1.C % 4 == 0),
                 "conv: c4 sources need stride 1 and channel counts %% 4 == 0");
+    // the streaming 1x1 kernel: tile-major sources, planar or 4-channel-interleaved (then Cout % 4 == 0 for a c4 destination)
     NND_REQUIRE(!io.dst_c4 || (io.dst_tiled && (L.Cout % 4 == 0 || (!io.bmap.ptr && !io.aux0.ptr && !io.aux1.ptr && !io.out1.ptr))),
                 "conv: c4 destination with per-pixel operands needs Cout %% 4 == 0");
     a.H = H; a.W = W; a.Cout = L.Cout; a.nchunks = L.nchunks; a.epi = epi; a.hidden = io.hidden;
@@ -540,7 +589,7 @@ int launch_conv(const ConvLayer& L, const float* blob, const ConvIO& io, int epi
     a.npos = cfg.npos; a.ngroups = cfg.ngroups;
     a.scale = io.scale;
     const bool no_stream = switches().no_conv1x1_stream;
-    if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && !io.src_c4 && !io.dst_c4 && !io.bmap.ptr &&
+    if (!no_stream && L.KH == 1 && L.KW == 1 && L.stride == 1 && io.src1.C == 0 && io.src_tiled && (!io.dst_c4 || L.Cout % 4 == 0) && !io.bmap.ptr &&
         (L.Cin == 64 || L.Cin == 96 || L.Cin == 128) &&
         (epi == EPI_LINEAR || epi == EPI_RELU || epi == EPI_SCALE || epi == EPI_AFFINE)) {
         const int ntiles = cfg.tiles_x * cfg.tiles_y, KQ = L.nchunks * L.CI_T / 8;

@@ -189,7 +189,7 @@ int launch_conv_split(const ConvLayer& L, const float* blob, const ConvIO& io, i
     const int Hin = io.Hin > 0 ? io.Hin : H, Win = io.Win > 0 ? io.Win : W;  // input size (stride 2: the caller passes it)
     NND_REQUIRE(L.stride == 1 ? (Hin == H && Win == W) : (H == (Hin + 1) / 2 && W == (Win + 1) / 2),
                 "conv_split: output %dx%d does not match input %dx%d at stride %d", H, W, Hin, Win, L.stride);
-    NND_REQUIRE(L.stride == 1 || (!io.src_c4 && io.src1.C == 0), "conv_split: stride 2 is built for one planar source");
+    NND_REQUIRE(L.stride == 1 || io.src1.C == 0, "conv_split: stride 2 is built for one source");
     NND_REQUIRE((long)(L.Cin + 64) * tiled_plane(Hin, Win) < (1L << 31), "conv_split: plane offsets exceed 32 bits");
     SplitCfg cfg;
     // FAST regime: any source layout the kernel addresses as plane + pixel offset — c4 tile-major (the refinement loops' own

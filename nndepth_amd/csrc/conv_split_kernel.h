@@ -116,7 +116,7 @@ struct SplitPipe {
 
 template <int KH, int KW, int NS, int P, int NU, bool FAST, bool SRC4, int AD_, int MAXT, int STR = 1>
 __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
-    static_assert(STR == 1 || (FAST && !SRC4 && (KH * KW == 9 || KH * KW == 1)), "stride 2: 3x3 / 1x1, FAST regime, planar sources");
+    static_assert(STR == 1 || (FAST && (KH * KW == 9 || KH * KW == 1)), "stride 2: 3x3 / 1x1, FAST regime");
     using Geo = SplitGeom<KH, KW, NS, STR>;
     constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
     constexpr int PC = Geo::PCI, NPOS = Geo::NPOS;
@@ -655,9 +655,13 @@ template <int KH, int KW, int NS>
 int launch_split_shape(const ConvArgs& a, const SplitCfg& cfg, dim3 grid, dim3 block, hipStream_t stream) {
     constexpr int FAD = split_fast_ad<KH, KW, NS>();
     if (cfg.P != 2) return NND_ERR_UNSUPPORTED;
-    if (cfg.stride == 2) {  // FAST, planar sources (checked by the host)
+    if (cfg.stride == 2) {  // FAST regime only; planar or 4-channel-interleaved (round 4: the encoder's tensors) sources
         if constexpr (KH * KW == 9 || KH * KW == 1) {
-            if (!cfg.fast || a.ls.ci == 4) return NND_ERR_UNSUPPORTED;
+            if (!cfg.fast) return NND_ERR_UNSUPPORTED;
+            if (a.ls.ci == 4) {
+                if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, true, FAD, 768, 2>(a, grid, block, cfg.lds, stream);
+                return launch_split_kernel<KH, KW, NS, 2, 4, true, true, FAD, 768, 2>(a, grid, block, cfg.lds, stream);
+            }
             if (cfg.nu <= 2) return launch_split_kernel<KH, KW, NS, 2, 2, true, false, FAD, 768, 2>(a, grid, block, cfg.lds, stream);
             return launch_split_kernel<KH, KW, NS, 2, 4, true, false, FAD, 768, 2>(a, grid, block, cfg.lds, stream);
         } else {

@@ -86,8 +86,10 @@ static void pack_conv_norm(const ConvLayer& L, const float* w, const float* bias
     }
 }
 
+// (x_c4 / y_c4: tile-major tensors with 4 channels interleaved, layout.h; the residual follows y's layout)
 static int run_conv_norm(const ConvLayer& L, const float* base, const float* x, int64_t xbs, bool x_tiled, const float* res,
-                         int64_t rbs, float* y, int64_t ybs, bool y_tiled, int flags, int B, int Hin, int Win, hipStream_t s) {
+                         int64_t rbs, float* y, int64_t ybs, bool y_tiled, int flags, int B, int Hin, int Win, hipStream_t s,
+                         bool x_c4 = false, bool y_c4 = false) {
     const int H = (Hin + L.stride - 1) / L.stride, W = (Win + L.stride - 1) / L.stride;
     ConvIO io{};
     io.src0 = Act{const_cast<float*>(x), xbs, L.Cin};
@@ -97,6 +99,8 @@ static int run_conv_norm(const ConvLayer& L, const float* base, const float* x, 
     io.flags = flags;
     io.src_tiled = x_tiled;
     io.dst_tiled = y_tiled;
+    io.src_c4 = x_tiled && x_c4;
+    io.dst_c4 = y_tiled && y_c4;
     return launch_conv(L, base, io, EPI_AFFINE, B, H, W, s);
 }
 
@@ -168,6 +172,22 @@ __global__ void __launch_bounds__(256) stem_kernel(const float* __restrict__ x, 
         const int y = ty0 + (st >> 2) * 4 + r, xx = tx0 + (st & 3) * 8 + cc;
         if (y >= H || xx >= W) continue;
         float* o = out + (long)n * obs + pix_off(lay, y, xx);
+        if (lay.ci == 4) {  // 4 channels interleaved: registers 4q..4q+3 of a block are one 16-B store
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co0 = j * 32 + 8 * q + 4 * h2;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(acc[i][j][4 * q + e], scale[co0 + e], shift[co0 + e]);
+                        v[e] = relu ? fmaxf(t, 0.f) : t;
+                    }
+                    *reinterpret_cast<float4*>(o + (long)co0 * lay.plane) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -518,8 +538,15 @@ int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, cons
     float* st_b = st_a + (int64_t)N * 256;
     float* st_c = st_b + (int64_t)N * 256;
     double* part = reinterpret_cast<double*>(st_c + (int64_t)N * 256);  // 8-byte aligned: every offset above is a multiple of 64 floats
+    // Round 4: with a split arithmetic (every 3x3 and stride-2 layer on conv_split, the stride-1 shortcuts and the output conv on
+    // the streaming 1x1 kernel) the activations between the layers keep 4 channels interleaved (layout.h "c4"): a staging unit is two
+    // 16-byte loads instead of eight 4-byte ones, an epilogue lane stores / reads its residual as 16 bytes — the layer1 convs were
+    // bound by the CU's vector-memory instruction rate (about 400 wave-instructions per 64-pixel workgroup, epilogue 17 of 37 us
+    // per workgroup: scripts/stamps_encoder.py).  The exact arithmetic (stride-2 layers on conv_mfma: planar sources only) and the
+    // instance-norm encoder (its statistics kernels walk channel planes) stay planar; NND_ENC_NO_C4 (diagnostic) keeps planar too.
+    const bool c4 = desc->arithmetic != 0 && !inorm && !switches().enc_no_c4;
     {  // stem -> buf[0]
-        const Lay lay = make_lay(h, w, true);
+        const Lay lay = make_lay(h, w, true, c4);
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 8);
         hipLaunchKernelGGL(stem_kernel, dim3(tiles_x * tiles_y, 1, N), dim3(256), 0, s, frames, frames_b, frames_b ? nsplit : N, packed + p.stem_w,
                            packed + p.stem_scale, packed + p.stem_shift, buf[0], (long)(64 * lay.plane), H, W, h, w, tiles_x, lay,
@@ -544,9 +571,9 @@ int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, cons
         float* sc = buf[(cur + 2) & 3];
         float* o = buf[(cur + 3) & 3];
         if (!inorm) {
-            NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 1, N, h, w, s));
-            NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s));
-            NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, sc, dim * pout, o, dim * pout, true, 3, N, ho, wo, s));
+            NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 1, N, h, w, s, c4, c4));
+            NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s, c4, c4));
+            NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, sc, dim * pout, o, dim * pout, true, 3, N, ho, wo, s, c4, c4));
         } else {  // raw convs + per-sample statistics; the shortcut is normalised inside the block's final apply pass
             NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 0, N, h, w, s));
             NND_TRY(in_stats(y, dim * pout, N, dim, ho, wo, eps, st_a, part, s));
@@ -562,7 +589,7 @@ int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, cons
     }
     const int64_t pl = tiled_plane(h, w);
     NND_TRY(run_conv_norm(p.out, packed + p.base_out, buf[cur], 128 * pl, true, nullptr, 0, fmap, (int64_t)desc->output_dim * h * w,
-                          false, 0, N, h, w, s));
+                          false, 0, N, h, w, s, c4, false));
     if (cnet_out)
         NND_TRY(run_conv_norm(p.cnet, packed + p.base_cnet, fmap, (int64_t)desc->output_dim * h * w, false, nullptr, 0, cnet_out,
                               (int64_t)desc->cnet_dim * h * w, false, 1, n_cnet, h, w, s));

@@ -37,6 +37,7 @@ static void load_switches() {
     s.lds_poison_on = on("NND_DEBUG_LDS_POISON");
     s.lds_poison = s.lds_poison_on ? (unsigned)strtoul(getenv("NND_DEBUG_LDS_POISON"), nullptr, 0) : 0u;
     s.lds_slack = getenv("NND_DEBUG_LDS_SLACK") ? atoi(getenv("NND_DEBUG_LDS_SLACK")) : 0;
+    s.enc_no_c4 = on("NND_ENC_NO_C4");
     s.no_slab3d = on("NND_NO_SLAB3D");
     s.slab3d_rounds = getenv("NND_SLAB3D_ROUNDS") ? atoi(getenv("NND_SLAB3D_ROUNDS")) : 0;
     g_sw = s;

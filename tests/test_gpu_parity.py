@@ -484,6 +484,32 @@ def test_c4_workspace_layout_is_bit_identical_to_planar(raft_sd, monkeypatch, ar
         assert torch.equal(x, y), (i, float((x - y).abs().max()))
 
 
+@pytest.mark.parametrize("arithmetic", ["fp16x2", "bf16x3"])
+def test_encoder_c4_layout_is_bit_identical_to_planar(raft_sd, monkeypatch, arithmetic):
+    """Round 4: with a split arithmetic the encoder's activations keep 4 channels interleaved (csrc/encoder.hip, layout.h) — 16-byte
+    staging loads, residual loads and stores, c4 variants of the stem epilogue, of the streaming 1x1 kernel and of the stride-2
+    split kernels.  A pure change of addresses: feature map and context projection must equal the planar run (NND_ENC_NO_C4) bit for
+    bit, on a ragged frame size (tiles cut by the image edge at every resolution) and at batch 2."""
+    from nndepth_amd import ops, weightgen
+    enc_sd = {k[len("fnet."):]: v for k, v in raft_sd.items() if k.startswith("fnet.")}
+    cnet_sd = {k[len("cnet_proj."):]: v for k, v in raft_sd.items() if k.startswith("cnet_proj.")}
+
+    def run():
+        eng = ops.EncoderEngine(256, "batch", 192, arithmetic).load(enc_sd, cnet_sd, device=DEV)
+        outs = []
+        for (B, H, W) in ((2, 104, 168), (1, 96, 160)):
+            f1, f2 = (x.to(DEV) for x in weightgen.synthetic_frames(21, B, H, W))
+            fm, cn = eng.forward(f1, n_cnet=B, frames_b=f2)
+            outs += [fm.clone(), cn.clone()]
+        return outs
+
+    a = run()
+    monkeypatch.setenv("NND_ENC_NO_C4", "1")
+    b = run()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
 def test_fused_mask_upsample_matches_unfused(raft_sd, monkeypatch):
     """The fused mask.2+softmax+upsample kernel (mask never written) == mask.2 conv followed by the
     standalone convex_upsample kernel, on the same loop (seam-by-seam path uses the unfused kernels)."""
