@@ -245,6 +245,57 @@ __global__ void __launch_bounds__(256) in_partial_kernel(const float* __restrict
     }
 }
 
+// The same for a tensor with 4 channels interleaved (layout.h): workgroup = (chunk, channel quad, sample); a thread visits the same
+// pixel groups in the same order as above and keeps four pairs of sums, so every channel's partials are bit for bit those of the
+// planar kernel.
+__global__ void __launch_bounds__(256) in_partial_c4_kernel(const float* __restrict__ x, long bs, int C, int H, int W, Lay lay,
+                                                            double* __restrict__ partial) {
+    __shared__ double sh[2][4][256];
+    const int k = blockIdx.x, cq = blockIdx.y, n = blockIdx.z;
+    const float* p = x + (long)n * bs + (long)cq * 4 * lay.plane;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    const long ngroups = lay.plane / 4;
+    for (long g = (long)k * 256 + threadIdx.x; g < ngroups; g += IN_CHUNKS * 256) {
+        const long t = g >> 3;
+        const int y = (int)(t / lay.TX) * 4 + (int)((g & 7) >> 1), x0 = (int)(t % lay.TX) * 8 + (int)(g & 1) * 4;
+        if (y >= H || x0 >= W) continue;
+        float4 v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = *reinterpret_cast<const float4*>(p + (g * 4 + e) * 4);  // pixel 4g + e: its 4 channels
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (x0 + e < W) {
+                const float vv[4] = {v4[e].x, v4[e].y, v4[e].z, v4[e].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = (double)vv[j];
+                    s[j] += v;
+                    q[j] += v * v;
+                }
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[0][j][threadIdx.x] = s[j];
+        sh[1][j][threadIdx.x] = q[j];
+    }
+    __syncthreads();
+    for (int r = 128; r > 0; r >>= 1) {
+        if ((int)threadIdx.x < r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sh[0][j][threadIdx.x] += sh[0][j][threadIdx.x + r];
+                sh[1][j][threadIdx.x] += sh[1][j][threadIdx.x + r];
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        double* o = partial + (((long)n * C + cq * 4 + threadIdx.x) * IN_CHUNKS + k) * 2;
+        o[0] = sh[0][threadIdx.x][0];
+        o[1] = sh[1][threadIdx.x][0];
+    }
+}
+
 __global__ void __launch_bounds__(256) in_final_kernel(const double* __restrict__ partial, int NC, int HW, float eps,
                                                        float* __restrict__ stats) {
     const int i = blockIdx.x * 256 + threadIdx.x;  // plane index n*C + c
@@ -302,10 +353,47 @@ __global__ void __launch_bounds__(256) in_apply_kernel(float* __restrict__ x, lo
     else *p = v[0];
 }
 
-static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, float eps, float* stats, double* partial, hipStream_t s) {
+// The same for 4 channels interleaved: one thread = the 4 channels of one pixel, each with its own (alpha, beta)
+__global__ void __launch_bounds__(256) in_apply_c4_kernel(float* __restrict__ x, long bs, const float* __restrict__ stats,
+                                                          const float* __restrict__ sc, long sbs, const float* __restrict__ sstats,
+                                                          int C, long plane, int relu) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // pixel slot of the tile-major plane (padding included: never read as data)
+    if (i >= plane) return;
+    const int cq = blockIdx.y, n = blockIdx.z;
+    const float4 st0 = *reinterpret_cast<const float4*>(stats + ((long)n * C + cq * 4) * 2);      // (a, b) of channels 0, 1
+    const float4 st1 = *reinterpret_cast<const float4*>(stats + ((long)n * C + cq * 4 + 2) * 2);  // ... 2, 3
+    const float a[4] = {st0.x, st0.z, st1.x, st1.z}, b[4] = {st0.y, st0.w, st1.y, st1.w};
+    float* p = x + (long)n * bs + (long)cq * 4 * plane + i * 4;
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    float v[4] = {t.x, t.y, t.z, t.w}, sv[4] = {0.f, 0.f, 0.f, 0.f}, as[4] = {0.f, 0.f, 0.f, 0.f}, bsft[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sc) {
+        const float4 s0 = *reinterpret_cast<const float4*>(sstats + ((long)n * C + cq * 4) * 2);
+        const float4 s1 = *reinterpret_cast<const float4*>(sstats + ((long)n * C + cq * 4 + 2) * 2);
+        as[0] = s0.x; as[1] = s0.z; as[2] = s1.x; as[3] = s1.z;
+        bsft[0] = s0.y; bsft[1] = s0.w; bsft[2] = s1.y; bsft[3] = s1.w;
+        const float4 u = *reinterpret_cast<const float4*>(sc + (long)n * sbs + (long)cq * 4 * plane + i * 4);
+        sv[0] = u.x; sv[1] = u.y; sv[2] = u.z; sv[3] = u.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float r = fmaf(v[k], a[k], b[k]);
+        if (relu) r = fmaxf(r, 0.f);
+        if (sc) r = fmaxf(fmaf(sv[k], as[k], bsft[k]) + r, 0.f);
+        v[k] = r;
+    }
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, float eps, float* stats, double* partial, hipStream_t s,
+                    bool c4 = false) {
     // in_partial_kernel reads 16 bytes per thread: a tile-major plane is a multiple of 32 floats, so only the base decides
     NND_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && bs % 4 == 0, "encoder: instance-norm statistics need a 16-byte aligned workspace");
-    hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, C, N), dim3(256), 0, s, x, (long)bs, C, H, W, make_lay(H, W, true), partial);
+    if (c4) {
+        NND_REQUIRE(C % 4 == 0, "encoder: 4-channel-interleaved statistics need C %% 4 == 0");
+        hipLaunchKernelGGL(in_partial_c4_kernel, dim3(IN_CHUNKS, C / 4, N), dim3(256), 0, s, x, (long)bs, C, H, W, make_lay(H, W, true), partial);
+    } else {
+        hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, C, N), dim3(256), 0, s, x, (long)bs, C, H, W, make_lay(H, W, true), partial);
+    }
     NND_LAUNCH_CHECK();
     hipLaunchKernelGGL(in_final_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const double*)partial, N * C, H * W, eps, stats);
     NND_LAUNCH_CHECK();
@@ -313,8 +401,17 @@ static int in_stats(const float* x, int64_t bs, int N, int C, int H, int W, floa
 }
 
 static int in_apply(float* x, int64_t bs, const float* stats, const float* sc, int64_t sbs, const float* sstats, int N, int C, int H,
-                    int W, bool relu, hipStream_t s) {
+                    int W, bool relu, hipStream_t s, bool c4 = false) {
     const long plane = tiled_plane(H, W);
+    if (c4) {
+        NND_REQUIRE(C % 4 == 0 && bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(stats) % 16 == 0 &&
+                        (!sc || (sbs % 4 == 0 && reinterpret_cast<uintptr_t>(sc) % 16 == 0 && reinterpret_cast<uintptr_t>(sstats) % 16 == 0)),
+                    "encoder: 4-channel-interleaved instance norm needs 16-byte aligned tensors and C %% 4 == 0");
+        hipLaunchKernelGGL(in_apply_c4_kernel, dim3((unsigned)cdiv64(plane, 256), C / 4, N), dim3(256), 0, s, x, (long)bs, stats, sc, (long)sbs,
+                           sstats, C, plane, relu ? 1 : 0);
+        NND_LAUNCH_CHECK();
+        return NND_OK;
+    }
     const bool v4 = plane % 4 == 0 && bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                     (!sc || (sbs % 4 == 0 && reinterpret_cast<uintptr_t>(sc) % 16 == 0));
     if (v4)
@@ -543,8 +640,9 @@ int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, cons
     // 16-byte loads instead of eight 4-byte ones, an epilogue lane stores / reads its residual as 16 bytes — the layer1 convs were
     // bound by the CU's vector-memory instruction rate (about 400 wave-instructions per 64-pixel workgroup, epilogue 17 of 37 us
     // per workgroup: scripts/stamps_encoder.py).  The exact arithmetic (stride-2 layers on conv_mfma: planar sources only) and the
-    // instance-norm encoder (its statistics kernels walk channel planes) stay planar; NND_ENC_NO_C4 (diagnostic) keeps planar too.
-    const bool c4 = desc->arithmetic != 0 && !inorm && !switches().enc_no_c4;
+    // same tensors under NND_ENC_NO_C4 (diagnostic) stay planar; the instance-norm statistics / apply kernels have c4 variants that visit the
+    // pixels in the planar kernels' order (bit-identical statistics).
+    const bool c4 = desc->arithmetic != 0 && !switches().enc_no_c4;
     {  // stem -> buf[0]
         const Lay lay = make_lay(h, w, true, c4);
         const int tiles_x = cdiv(w, 32), tiles_y = cdiv(h, 8);
@@ -559,8 +657,8 @@ int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, cons
         if ((rc = (x)) != NND_OK) return rc; \
     } while (0)
     if (inorm) {  // norm1 + ReLU of the stem
-        NND_TRY(in_stats(buf[0], 64 * tiled_plane(h, w), N, 64, h, w, eps, st_a, part, s));
-        NND_TRY(in_apply(buf[0], 64 * tiled_plane(h, w), st_a, nullptr, 0, nullptr, N, 64, h, w, true, s));
+        NND_TRY(in_stats(buf[0], 64 * tiled_plane(h, w), N, 64, h, w, eps, st_a, part, s, c4));
+        NND_TRY(in_apply(buf[0], 64 * tiled_plane(h, w), st_a, nullptr, 0, nullptr, N, 64, h, w, true, s, c4));
     }
     for (int i = 0; i < ENC_BLOCKS; ++i) {
         const int st = p.strides[i], cin = p.inpl[i], dim = p.planes[i];
@@ -575,14 +673,14 @@ int nnd_encoder_forward2(const nnd_encoder_desc* desc, const float* packed, cons
             NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s, c4, c4));
             NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, sc, dim * pout, o, dim * pout, true, 3, N, ho, wo, s, c4, c4));
         } else {  // raw convs + per-sample statistics; the shortcut is normalised inside the block's final apply pass
-            NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 0, N, h, w, s));
-            NND_TRY(in_stats(y, dim * pout, N, dim, ho, wo, eps, st_a, part, s));
-            NND_TRY(in_apply(y, dim * pout, st_a, nullptr, 0, nullptr, N, dim, ho, wo, true, s));
-            NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s));
-            NND_TRY(in_stats(sc, dim * pout, N, dim, ho, wo, eps, st_b, part, s));
-            NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, nullptr, 0, o, dim * pout, true, 0, N, ho, wo, s));
-            NND_TRY(in_stats(o, dim * pout, N, dim, ho, wo, eps, st_c, part, s));
-            NND_TRY(in_apply(o, dim * pout, st_c, sc, dim * pout, st_b, N, dim, ho, wo, true, s));
+            NND_TRY(run_conv_norm(p.c1[i], packed + p.base1[i], x, cin * pin, true, nullptr, 0, y, dim * pout, true, 0, N, h, w, s, c4, c4));
+            NND_TRY(in_stats(y, dim * pout, N, dim, ho, wo, eps, st_a, part, s, c4));
+            NND_TRY(in_apply(y, dim * pout, st_a, nullptr, 0, nullptr, N, dim, ho, wo, true, s, c4));
+            NND_TRY(run_conv_norm(p.ds[i], packed + p.based[i], x, cin * pin, true, nullptr, 0, sc, dim * pout, true, 0, N, h, w, s, c4, c4));
+            NND_TRY(in_stats(sc, dim * pout, N, dim, ho, wo, eps, st_b, part, s, c4));
+            NND_TRY(run_conv_norm(p.c2[i], packed + p.base2[i], y, dim * pout, true, nullptr, 0, o, dim * pout, true, 0, N, ho, wo, s, c4, c4));
+            NND_TRY(in_stats(o, dim * pout, N, dim, ho, wo, eps, st_c, part, s, c4));
+            NND_TRY(in_apply(o, dim * pout, st_c, sc, dim * pout, st_b, N, dim, ho, wo, true, s, c4));
         }
         cur = (cur + 3) & 3;
         h = ho; w = wo;

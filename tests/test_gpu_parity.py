@@ -503,9 +503,18 @@ def test_encoder_c4_layout_is_bit_identical_to_planar(raft_sd, monkeypatch, arit
             outs += [fm.clone(), cn.clone()]
         return outs
 
-    a = run()
+    def run_in():  # CREStereo's instance-norm encoder: c4 variants of the statistics / apply kernels (same summation order)
+        from nndepth_amd.cre_stereo import CREStereoBase
+        m = CREStereoBase(iters=2, arithmetic=arithmetic)
+        weightgen.fill_module_(m)
+        m = m.to(DEV).eval()
+        f1, f2 = (x.to(DEV) for x in weightgen.synthetic_frames(22, 1, 136, 200))
+        return [t_.clone() for t_ in m.forward_fnet(f1, f2)]
+
+    a = run() + run_in()
     monkeypatch.setenv("NND_ENC_NO_C4", "1")
-    b = run()
+    b = run() + run_in()
+    assert len(a) == len(b) == 6
     for i, (x, y) in enumerate(zip(a, b)):
         assert torch.equal(x, y), (i, float((x - y).abs().max()))
 
