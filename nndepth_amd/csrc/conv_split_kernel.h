@@ -121,7 +121,11 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
     constexpr int NT = KH * KW, PH = KH / 2, PW = KW / 2;
     constexpr int PC = Geo::PCI, NPOS = Geo::NPOS;
 #ifndef NND_SPLIT_NO_PIPE
-    constexpr bool PIPE = FAST && SplitPipe<NT, P, NU>::ON;  // the pipelined walk below (round 4)
+    // the pipelined walk below (round 4) — for 4-channel-interleaved sources (a staging unit is two 16-byte loads).  With planar
+    // sources a unit is eight 4-byte loads: issued as one burst behind unit UL they queue in front of the weight ring, and the
+    // regulariser's grouped layers (NU = 4: 32 loads per thread) measured slower than with round 3's walk (conv3_up 142 -> 185 us,
+    // conv3.1 72 -> 82: profiles/r04_igev_regulariser_layers_fp16x2.txt vs r03_*), so those keep it.
+    constexpr bool PIPE = FAST && SRC4 && SplitPipe<NT, P, NU>::ON;
 #else
     constexpr bool PIPE = false;
 #endif
