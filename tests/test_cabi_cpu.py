@@ -87,11 +87,57 @@ def test_update_block_pack_and_sizes_host():
     assert np.array_equal(rec[:256, :36, 0], sd["u.encoder.convc1.weight"].numpy()[:, :, 0, 0])
     assert np.array_equal(bias[:256], sd["u.encoder.convc1.bias"].numpy())
     assert lib.nnd_update_block_workspace_floats(C.byref(eng.desc), 1, 68, 120) > 2000 * 68 * 120
-    bad = UpdateBlockDesc(100, 64, 36, 1, 576, 0)  # hidden_dim not a multiple of 32
+    bad = UpdateBlockDesc(100, 64, 36, 1, 576, 0, 0, 0, 0)  # hidden_dim not a multiple of 32
     assert lib.nnd_update_block_packed_floats(C.byref(bad)) < 0
     assert b"hidden_dim" in lib.nnd_last_error()
     with pytest.raises(NndError):
         ops.UpdateBlockEngine(128, 64, 36, 3, 576)  # flow_channels must be 1 or 2
+
+
+def test_descriptors_carry_their_size_and_fp16x2_layers_their_scale_slot():
+    """Round 4: (i) every descriptor starts with struct_size and an entry point refuses another size or unknown flags; (ii) which
+    layers take the split arithmetic is the descriptor's split_layers (blob layout = function of the descriptor alone); (iii) a
+    packed fp16x2 layer carries the 4-float slot {2^-(s+xs), 2^xs, record, 2^-s} behind its bias with xs = 2 until calibrated
+    (csrc/split_arith.h: SPLIT_TAIL_*, include/nndepth_amd.h "fp16x2 activation range")."""
+    from nndepth_amd import ops, weightgen
+    from nndepth_amd._lib import lib, UpdateBlockDesc, EncoderDesc, Conv3dDesc
+    from oracle import torch_ref as R
+    eng = ops.UpdateBlockEngine(128, 64, 36, 1, 576, "sep_conv", "fp16x2")
+    assert eng.desc.struct_size == C.sizeof(UpdateBlockDesc) == 40
+    n_full = lib.nnd_update_block_packed_floats(C.byref(eng.desc))
+    assert n_full > 0
+    eng.desc.struct_size = 28  # a caller compiled against round 3's header
+    assert lib.nnd_update_block_packed_floats(C.byref(eng.desc)) < 0 and b"struct_size" in lib.nnd_last_error()
+    eng.desc.struct_size = C.sizeof(UpdateBlockDesc)
+    eng.desc.flags = 8
+    assert lib.nnd_update_block_packed_floats(C.byref(eng.desc)) < 0 and b"flags" in lib.nnd_last_error()
+    eng.desc.flags = 0
+    for D in (EncoderDesc(256, 1, 192, 2, 0), Conv3dDesc(16, 8, 0, 1, 2, 0)):
+        assert D.struct_size == C.sizeof(type(D))
+    bad = EncoderDesc(256, 1, 192, 2, 0)
+    bad.struct_size = 16
+    assert lib.nnd_encoder_packed_floats(C.byref(bad)) < 0 and b"struct_size" in lib.nnd_last_error()
+    # split_layers: only encoder.convc2 (bit 1) in the split arithmetic -> another blob size, same for pack and forward by construction
+    sub = UpdateBlockDesc(128, 64, 36, 1, 576, 0, 2, 1 << 1, 0)
+    n_sub = lib.nnd_update_block_packed_floats(C.byref(sub))
+    assert 0 < n_sub != n_full
+    # scale slots: one per fp16x2 convolution, -1 for the others (convc1's 36 planes stay exact fp32)
+    n = lib.nnd_update_block_scale_slots(C.byref(eng.desc), None, 0)
+    offs = (C.c_int64 * n)()
+    assert lib.nnd_update_block_scale_slots(C.byref(eng.desc), offs, n) == n
+    names = [lib.nnd_conv_name(C.byref(eng.desc), i).decode() for i in range(lib.nnd_num_convs(C.byref(eng.desc)))]
+    assert offs[names.index("encoder.convc1")] == -1 and offs[names.index("encoder.convc2")] > 0
+    sd = weightgen.fill_state_dict(R.update_block_spec("u", 128, 36, 64, 1, 8))
+    blob = eng.pack_host(sd, "u.").numpy()
+    slots = [o for o in offs if o >= 0]
+    assert len(slots) >= 12 and len(set(slots)) == len(slots)
+    for o in slots:
+        osc, xsc, rec, wsinv = blob[o:o + 4]
+        assert xsc == 4.0 and rec == 0.0 and osc == wsinv / xsc
+        assert np.log2(wsinv) == np.round(np.log2(wsinv))  # an exact power of two
+    wmax = np.abs(sd["u.encoder.convc2.weight"].numpy()).max()
+    wsinv = blob[offs[names.index("encoder.convc2")] + 3]
+    assert 2.0 ** 13 <= wmax / wsinv < 2.0 ** 14  # weights scaled into the top of fp16's range
 
 
 def test_null_and_shape_errors_do_not_crash():
