@@ -40,7 +40,7 @@ void set_error(const char* fmt, ...);
 // loaded and again only by nnd_reload_switches(); the hot path never calls getenv.  They select between kernels that the parity
 // tests prove equivalent, never a non-HIP path.
 struct Switches {
-    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, no_conv1x1_stream,
+    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, corr_build_no_ksplit, igev_squeeze_v1, igev_squeeze_walk, no_conv1x1_stream,
         conv_verbose, debug_sync;
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies

@@ -267,9 +267,115 @@ __global__ void __launch_bounds__(256) corr1d_build_lds_kernel(const float* __re
     }
 }
 
+// Small problems (one pair at 1/4 resolution: 272 workgroups of the kernel above = one wave per SIMD, every load latency
+// exposed): one 32 x 32 output tile per workgroup and the channel range split over its 4 waves, 4 x the waves in flight.
+// Operands go global -> register (lane l of a k-step holds f[2s + l/32][x0 + l%32]: one 128-byte run per half wave), all
+// loads of a KB-step batch issued before its first MFMA; the four partial tiles meet in LDS and are summed in wave order
+// (q = 0..3: the result differs from the full-K kernels in the last bits, deterministically).  Pooling stays inside the
+// tile (tile origins are multiples of 32 >= 2^levels) through lane exchanges; every level leaves as row segments.
+// 1-D grid, remapped so that the tiles of one image row (which share their f1 / f2 row) run on one XCD's L2.
+template <int KB>
+__global__ void __launch_bounds__(256) corr1d_build_ksplit_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                                  float* __restrict__ pyr, PyrLayout L, int C, int H, int W,
+                                                                  float rscale_div, int Ctot, int G, int nwg) {
+    __shared__ float red[4][32][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int per_xcd = (nwg + 7) >> 3;
+    const int wg = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (wg >= nwg) return;
+    const int nt = (W + 31) / 32;
+    const int t2 = wg % nt, t1 = (wg / nt) % nt, h = (wg / (nt * nt)) % H, b = wg / (nt * nt * H);
+    const long HW = (long)H * W;
+    const long chan0 = (long)(b / G) * Ctot + (long)(b % G) * C;
+    const float* a_base = f1 + chan0 * HW + (long)h * W;
+    const float* b_base = f2 + chan0 * HW + (long)h * W;
+    const int w1_0 = t1 * 32, w2_0 = t2 * 32;
+    const int w1 = w1_0 + l31, w2 = w2_0 + l31;
+    const bool a_ok = w1 < W, b_ok = w2 < W;
+    const int w1c = min(w1, W - 1), w2c = min(w2, W - 1);
+    const int nk = (C + 1) / 2, per = (nk + 3) / 4;
+    const int s_begin = min(wave * per, nk), s_end = min(s_begin + per, nk);
+    const int nbatch = (s_end - s_begin + KB - 1) / KB;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float av[2][KB], bv[2][KB];
+    auto load = [&](int bt, float* a, float* bb) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int cc = min((s_begin + bt * KB + i) * 2 + h2, C - 1);
+            a[i] = a_base[cc * HW + w1c];
+            bb[i] = b_base[cc * HW + w2c];
+        }
+    };
+    auto mma = [&](int bt, const float* a, const float* bb) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+            const int s = s_begin + bt * KB + i;
+            const bool k_ok = s < s_end && s * 2 + h2 < C;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && k_ok) ? a[i] : 0.f, (b_ok && k_ok) ? bb[i] : 0.f, acc, 0, 0, 0);
+        }
+    };
+    if (nbatch > 0) load(0, av[0], bv[0]);
+    for (int bt = 0; bt < nbatch; bt += 2) {
+        if (bt + 1 < nbatch) load(bt + 1, av[1], bv[1]);
+        mma(bt, av[0], bv[0]);
+        if (bt + 1 < nbatch) {
+            if (bt + 2 < nbatch) load(bt + 2, av[0], bv[0]);
+            mma(bt + 1, av[1], bv[1]);
+        }
+    }
+    // partial tile of wave q -> red[q][row'][col], row' = row with bit 0 ^= bit 2: the two half waves of a store (rows r, r + 4)
+    // land in different halves of the 64 banks
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+        red[wave][row ^ ((row >> 2) & 1)][l31] = acc[reg];
+    }
+    __syncthreads();
+    const int col = tid & 31, rg = tid >> 5;  // thread: column `col` of rows 4 rg .. 4 rg + 3; a half wave = one row group
+    const int wcol = w2_0 + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * rg + j, rp = row ^ ((row >> 2) & 1);
+        float v = ((red[0][rp][col] + red[1][rp][col]) + red[2][rp][col]) + red[3][rp][col];
+        v = v / rscale_div;
+        const int ww1 = w1_0 + row;
+        const bool row_ok = ww1 < W;
+        const long prow = ((long)b * H + h) * W + ww1;  // pyramid row of pixel (b,h,w1)
+        if (row_ok && wcol < W) pyr[L.off[0] + prow * L.width[0] + wcol] = v;
+        int wcur = wcol;
+#pragma unroll
+        for (int l = 1; l < MAX_LEVELS; ++l) {
+            if (l >= L.nlev) break;
+            const float other = __shfl_xor(v, 1 << (l - 1));
+            v = (v + other) * 0.5f;
+            wcur >>= 1;
+            const bool owner = (col & ((1 << l) - 1)) == 0;
+            if (row_ok && owner && wcur < L.width[l]) pyr[L.off[l] + prow * L.width[l] + wcur] = v;
+        }
+    }
+}
+
+// launches the k-split kernel when the problem is small enough that the LDS-staged kernel leaves the SIMDs with one wave
+// each (fewer than 4 of its workgroups per CU) and the channel range is long enough to split; NND_CORR_BUILD_NO_KSPLIT: never
+static bool corr1d_build_ksplit_launch(const float* f1, const float* f2, float* pyr, const PyrLayout& L, int C, int H, int W, int B,
+                                       float div, int Ctot, int G, hipStream_t stream, int* rc) {
+    const long nt = cdiv(W, 32), lds_wgs = nt * H * B * G, nwg = lds_wgs * nt;
+    if (switches().corr_build_v1 || switches().corr_build_no_ksplit || C < 32 || lds_wgs >= 1024 || nwg > (1 << 24)) return false;
+    const unsigned grid = (unsigned)(8 * cdiv((int)nwg, 8));
+    // batches of 8 k-steps, two in flight (32 loads per lane): 96 VGPRs = 5 waves per SIMD, so the 4.25 workgroups per CU of one
+    // pair at 68x120 are resident at once (batches of 16: 116 VGPRs, a fifth workgroup waits for a slot: 21.3 vs 19.7 us)
+    hipLaunchKernelGGL(corr1d_build_ksplit_kernel<8>, dim3(grid), dim3(256), 0, stream, f1, f2, pyr, L, C, H, W, div, Ctot, G, (int)nwg);
+    *rc = hipGetLastError() == hipSuccess ? NND_OK : NND_ERR_HIP;
+    return true;
+}
+
 // launches corr1d_build_lds_kernel when the shape fits its staging plan; false: the caller uses corr1d_build_kernel
 static bool corr1d_build_lds_launch(const float* f1, const float* f2, float* pyr, const PyrLayout& L, int C, int H, int W, int B,
                                     float div, int Ctot, int G, hipStream_t stream, int* rc) {
+    if (corr1d_build_ksplit_launch(f1, f2, pyr, L, C, H, W, B, div, Ctot, G, stream, rc)) return true;
     const int ntile = cdiv(W, 32), WP = ntile * 32, NT = cdiv(ntile, 4);
     int KC = C >= 32 ? 32 : ((C + 1) / 2) * 2;
     if (C >= 64 && cdiv(64 * (8 + WP / 4), 256) <= CB_MAXLD) KC = 64;  // fewer, longer chunks: the next chunk's loads get more cover
@@ -1319,12 +1425,98 @@ struct SqueezeArgs {
     float bias;
 };
 
+// Soft-argmin over the candidates of SQ_PX pixels whose logits (without the bias) sit in acc[j][p], candidate tid + 256 j:
+// block reductions for the maxima, then the reference's evaluation order (see softargmin_kernel) through `es` = SQ_PX x D
+// floats of LDS that no thread reads any more (the function opens with a barrier).  All 256 threads call it.
+template <int DPT>
+__device__ __forceinline__ void squeeze_softargmin_tail(float (&acc)[DPT][SQ_PX], float bias, float* es, float* __restrict__ out_row,
+                                                        int w0, int W, int D) {
+    __shared__ float red[4][SQ_PX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // soft-argmin over the candidates: block reductions (max, sum of exp, sum of d*exp) for the SQ_PX pixels at once
+    auto block_reduce = [&](float (&v)[SQ_PX], bool is_max) {
+#pragma unroll
+        for (int p = 0; p < SQ_PX; ++p) {
+            float x = v[p];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float y = __shfl_xor(x, o);
+                x = is_max ? fmaxf(x, y) : x + y;
+            }
+            v[p] = x;
+        }
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int p = 0; p < SQ_PX; ++p) red[wave][p] = v[p];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < SQ_PX; ++p)
+            v[p] = is_max ? fmaxf(fmaxf(red[0][p], red[1][p]), fmaxf(red[2][p], red[3][p])) : (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
+    };
+    float mx[SQ_PX];
+#pragma unroll
+    for (int p = 0; p < SQ_PX; ++p) {
+        mx[p] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j)
+            if (tid + 256 * j < D) mx[p] = fmaxf(mx[p], acc[j][p] + bias);
+    }
+    block_reduce(mx, true);
+    // the reference's evaluation order (see softargmin_kernel): the staged rows are dead, `sm` now holds e[p][d] = exp(logit - max)
+    __shared__ float ssum[SQ_PX], bsum[SQ_PX][33];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid + 256 * j;
+        if (d < D)
+#pragma unroll
+            for (int p = 0; p < SQ_PX; ++p) es[p * D + d] = expf(acc[j][p] + bias - mx[p]);
+    }
+    __syncthreads();
+    if (tid < SQ_PX) {  // softmax denominator: strictly in order of d
+        float sden = 0.f;
+        for (int d = 0; d < D; ++d) sden += es[tid * D + d];
+        ssum[tid] = sden;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid + 256 * j;
+        if (d < D)
+#pragma unroll
+            for (int p = 0; p < SQ_PX; ++p) es[p * D + d] = (float)d * (es[p * D + d] / ssum[p]);  // disp * softmax: a product, then summed
+    }
+    __syncthreads();
+    {  // block sums of 16 consecutive candidates, in order (thread = pixel x block; D <= 512: at most 32 blocks)
+        const int p = tid >> 5, blk = tid & 31;
+        if (blk * 16 + 16 <= D) {
+            float bs = 0.f;
+            for (int j = 0; j < 16; ++j) bs += es[p * D + blk * 16 + j];
+            bsum[p][blk] = bs;
+        }
+    }
+    __syncthreads();
+    if (tid < SQ_PX && w0 + tid < W) {  // the levels of ATen's cascade: block sums in order, every 16 blocks into the next level
+        const int nb = D >> 4;
+        float lvl1 = 0.f, lvl2 = 0.f, tail = 0.f;
+        for (int blk = 0; blk < nb; ++blk) {
+            lvl1 += bsum[tid][blk];
+            if (((blk + 1) & 15) == 0) {
+                lvl2 += lvl1;
+                lvl1 = 0.f;
+            }
+        }
+        for (int d = nb * 16; d < D; ++d) tail += es[tid * D + d];
+        out_row[w0 + tid] = -((tail + lvl1) + lvl2);
+    }
+}
+
 template <int DPT>
 __global__ void __launch_bounds__(256) igev_squeeze_softargmin_kernel(const float* __restrict__ geo, float* __restrict__ out,
                                                                       SqueezeArgs a, int G, int H, int W, int D) {
     extern __shared__ float sm[];  // [3][SQ_PX + 2][D + 2]
-    __shared__ float red[4][SQ_PX];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     // XCD-aware mapping: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each); XCD x gets the band of
     // image rows [x*band, (x+1)*band), so the three rows a workgroup shares with its vertical neighbours stay in one L2
     const int nx = (W + SQ_PX - 1) / SQ_PX, band = (H + 7) / 8;
@@ -1408,83 +1600,219 @@ __global__ void __launch_bounds__(256) igev_squeeze_softargmin_kernel(const floa
             }
         }
     }
-    // soft-argmin over the candidates: block reductions (max, sum of exp, sum of d*exp) for the SQ_PX pixels at once
-    auto block_reduce = [&](float (&v)[SQ_PX], bool is_max) {
+    squeeze_softargmin_tail<DPT>(acc, a.bias, sm, out + ((long)b * H + h) * W, w0, W, D);  // the staged rows are dead: sm holds e[p][d]
+}
+
+// The same squeezer, walking down the image: the kernel above fetches 3 x (SQ_PX + 2) neighbour rows per group for the SQ_PX
+// pixels of ONE image row (3.75 x the volume through L1) and runs one soft-argmin (with its two strictly sequential sums over
+// the candidates, 8 busy lanes) per row.  Here a workgroup owns SQ_PX columns x R image rows and visits the R + 2 input rows
+// in order; each (row, group) slab of SQ_PX + 2 columns x D candidates is staged ONCE and feeds the three output rows it
+// neighbours (kh = 2, 1, 0) from three accumulator sets, which rotate when a row is done: (1 + 2/SQ_PX)(1 + 2/R) x the
+// volume, every LDS value read feeds 27 FMAs instead of 9.  Slab s + 1 is fetched into registers while slab s is multiplied
+// and lands in the other LDS buffer: one barrier per slab.  Finished rows park their logits in LDS and the soft-argmin runs
+// for SQW_TB rows at once (SQW_TB x SQ_PX sequential chains side by side instead of SQ_PX).  D <= 256, D % 4 == 0.
+// The sum over (g, kh, kw, kd) runs in the order (kh, g, column, kw, kd), one FMA per term, instead of (g, kh, column, kw,
+// [kd]) with the three kd terms added first: last-bit differences in the logits; the soft-argmin arithmetic is the same.
+constexpr int SQW_TB = 4, SQW_P = 4, SQW_T = 512, SQW_PXT = SQ_PX / 2;
+static_assert(SQW_P % 2 == 0, "the LDS buffer of a slab is its ring slot's parity");
+// one slab into the accumulators of a thread: candidate d, pixels p0 .. p0 + SQW_PXT - 1 of the strip (slab columns p0 .. p0 + SQW_PXT + 1)
+template <int MASK>
+__device__ __forceinline__ void squeeze_walk_slab(const float* __restrict__ cols, int DS, const float* __restrict__ wg,
+                                                  float (&acc)[3][SQW_PXT]) {
 #pragma unroll
-        for (int p = 0; p < SQ_PX; ++p) {
-            float x = v[p];
+    for (int c = 0; c < SQW_PXT + 2; ++c) {
+        const float* row = cols + c * DS;  // candidate d - 1 of column p0 + c
+        const float r0 = row[0], r1 = row[1], r2 = row[2];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float y = __shfl_xor(x, o);
-                x = is_max ? fmaxf(x, y) : x + y;
+        for (int t = 0; t < 3; ++t) {
+            if (!((MASK >> t) & 1)) continue;
+            const int kh = 2 - t;  // accumulator set t belongs to output row r - 1 + t, which sees input row r as its kh = 2 - t
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int p = c - kw;
+                if (p >= 0 && p < SQW_PXT) {
+                    acc[t][p] = fmaf(wg[0 * 9 + kh * 3 + kw], r0, acc[t][p]);
+                    acc[t][p] = fmaf(wg[1 * 9 + kh * 3 + kw], r1, acc[t][p]);
+                    acc[t][p] = fmaf(wg[2 * 9 + kh * 3 + kw], r2, acc[t][p]);
+                }
             }
-            v[p] = x;
         }
-        __syncthreads();
-        if (lane == 0)
-#pragma unroll
-            for (int p = 0; p < SQ_PX; ++p) red[wave][p] = v[p];
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < SQ_PX; ++p)
-            v[p] = is_max ? fmaxf(fmaxf(red[0][p], red[1][p]), fmaxf(red[2][p], red[3][p])) : (red[0][p] + red[1][p]) + (red[2][p] + red[3][p]);
-    };
-    float mx[SQ_PX];
-#pragma unroll
-    for (int p = 0; p < SQ_PX; ++p) {
-        mx[p] = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < DPT; ++j)
-            if (tid + 256 * j < D) mx[p] = fmaxf(mx[p], acc[j][p] + a.bias);
     }
-    block_reduce(mx, true);
-    // the reference's evaluation order (see softargmin_kernel): the staged rows are dead, `sm` now holds e[p][d] = exp(logit - max)
-    __shared__ float ssum[SQ_PX], bsum[SQ_PX][33];
-    float* es = sm;  // [SQ_PX][D] <= 3 * (SQ_PX + 2) * (D + 2) floats
+}
+
+// soft-argmin of `nrow` parked rows (lg[(row * SQ_PX + p) * DP + d] = logit incl. bias) in the reference's evaluation order
+// (softargmin_kernel): max, e = exp(l - max), sum of e strictly in order of d, terms d * (e / sum), ATen's cascade over them.
+// The two ordered sums are one chain per (row, pixel), spread over the eight waves.  All threads call it; opens with a barrier.
+__device__ __forceinline__ void squeeze_walk_softargmin(float* lg, int DP, int D, int nrow, float* __restrict__ out_row0, int W, int w0) {
+    __shared__ float mxs[SQW_TB * SQ_PX], sums[SQW_TB * SQ_PX];
+    constexpr int NW = SQW_T / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dl = tid & 255, half = tid >> 8;
+    const int npair = nrow * SQ_PX;
     __syncthreads();
+    for (int q = wave; q < npair; q += NW) {
+        float m = -INFINITY;
+        for (int dd = lane; dd < D; dd += 64) m = fmaxf(m, lg[q * DP + dd]);
 #pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-        const int d = tid + 256 * j;
-        if (d < D)
-#pragma unroll
-            for (int p = 0; p < SQ_PX; ++p) es[p * D + d] = expf(acc[j][p] + a.bias - mx[p]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) mxs[q] = m;
     }
     __syncthreads();
-    if (tid < SQ_PX) {  // softmax denominator: strictly in order of d
+    if (dl < D)
+        for (int q = half; q < npair; q += 2) lg[q * DP + dl] = expf(lg[q * DP + dl] - mxs[q]);
+    __syncthreads();
+    const int cq = lane * NW + wave;  // chain of this thread (the first lanes of every wave)
+    const bool chain = lane < SQW_TB * SQ_PX / NW && cq < npair;
+    if (chain) {  // 4 x 16 bytes per step: the LDS latency is paid once per 16 ordered adds
+        const float4* e4 = reinterpret_cast<const float4*>(lg + cq * DP);
+        const int n4 = D >> 2;
         float sden = 0.f;
-        for (int d = 0; d < D; ++d) sden += es[tid * D + d];
-        ssum[tid] = sden;
-    }
-    __syncthreads();
+        for (int i = 0; i < n4; i += 4) {
+            float4 v[4];
 #pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-        const int d = tid + 256 * j;
-        if (d < D)
+            for (int k = 0; k < 4; ++k) v[k] = e4[min(i + k, n4 - 1)];
 #pragma unroll
-            for (int p = 0; p < SQ_PX; ++p) es[p * D + d] = (float)d * (es[p * D + d] / ssum[p]);  // disp * softmax: a product, then summed
-    }
-    __syncthreads();
-    {  // block sums of 16 consecutive candidates, in order (thread = pixel x block; D <= 512: at most 32 blocks)
-        const int p = tid >> 5, blk = tid & 31;
-        if (blk * 16 + 16 <= D) {
-            float bs = 0.f;
-            for (int j = 0; j < 16; ++j) bs += es[p * D + blk * 16 + j];
-            bsum[p][blk] = bs;
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n4) sden += v[k].x, sden += v[k].y, sden += v[k].z, sden += v[k].w;
         }
+        sums[cq] = sden;
     }
     __syncthreads();
-    if (tid < SQ_PX && w0 + tid < W) {  // the levels of ATen's cascade: block sums in order, every 16 blocks into the next level
+    if (dl < D)
+        for (int q = half; q < npair; q += 2) lg[q * DP + dl] = (float)dl * (lg[q * DP + dl] / sums[q]);
+    __syncthreads();
+    if (chain) {
+        const int p = cq % SQ_PX, row = cq / SQ_PX;
+        const float4* t4 = reinterpret_cast<const float4*>(lg + cq * DP);
+        float lvl1 = 0.f, lvl2 = 0.f, tail = 0.f;  // aten_cascade_sum with the 16 terms of a block read as 4 x 16 bytes
         const int nb = D >> 4;
-        float lvl1 = 0.f, lvl2 = 0.f, tail = 0.f;
         for (int blk = 0; blk < nb; ++blk) {
-            lvl1 += bsum[tid][blk];
+            float4 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = t4[4 * blk + k];
+            float bs = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bs += x[k].x, bs += x[k].y, bs += x[k].z, bs += x[k].w;
+            lvl1 += bs;
             if (((blk + 1) & 15) == 0) {
                 lvl2 += lvl1;
                 lvl1 = 0.f;
             }
         }
-        for (int d = nb * 16; d < D; ++d) tail += es[tid * D + d];
-        out[((long)b * H + h) * W + w0 + tid] = -((tail + lvl1) + lvl2);
+        for (int i = 4 * nb; i < (D >> 2); ++i) {
+            const float4 x = t4[i];
+            tail += x.x, tail += x.y, tail += x.z, tail += x.w;
+        }
+        const float v = (tail + lvl1) + lvl2;
+        if (w0 + p < W) out_row0[(long)row * W + w0 + p] = -v;
+    }
+}
+
+__global__ void __launch_bounds__(SQW_T) igev_squeeze_walk_kernel(const float* __restrict__ geo, float* __restrict__ out, SqueezeArgs a,
+                                                                  int G, int H, int W, int D, int R, int nwg) {
+    extern __shared__ float sm[];  // slabs [2][(SQ_PX + 2) * DS + 4], then the parked logits [SQW_TB * SQ_PX][DP]
+    const int tid = threadIdx.x, dl = tid & 255, half = tid >> 8;  // thread: candidate dl, pixels 4 half .. 4 half + 3
+    const int per_xcd = (nwg + 7) >> 3;  // consecutive logical ids (strips of one band, then the next band) share one XCD's L2
+    const int wg_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (wg_id >= nwg) return;
+    const int nx = (W + SQ_PX - 1) / SQ_PX, nband = (H + R - 1) / R;
+    const int w0 = (wg_id % nx) * SQ_PX, band = (wg_id / nx) % nband, b = wg_id / (nx * nband);
+    const int h0 = band * R, hend = min(h0 + R, H);
+    // slab row c: [c * DS, c * DS + 4) pad (candidate -1 at +3), then D candidates; candidate D = the next row's first pad float
+    constexpr int NROW = SQ_PX + 2, NL = (NROW * 64 + SQW_T - 1) / SQW_T;
+    const int DS = D + 4, nq = D >> 2, SLAB = NROW * DS + 4;
+    const int DP = ((D >> 2) & 1) ? D : D + 4;  // odd number of 16-byte units per parked row: the chains' b128 reads spread over the banks
+    float* lg = sm + 2 * SLAB;
+    float acc[3][SQW_PXT];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int p = 0; p < SQW_PXT; ++p) acc[t][p] = 0.f;
+    const int rlo = max(h0 - 1, 0), rhi = min(hend, H - 1);  // input rows that exist
+    const int nslab = (rhi - rlo + 1) * G;
+    // SQW_P slabs are on their way or parked in registers at any time; the register ring is indexed statically, so the slab
+    // loop is unrolled SQW_P times.  The 16-byte units of a thread: slab-invariant offsets.
+    float4 stage[SQW_P][NL];
+    int src_off[NL], dst_off[NL];  // floats from the slab's (row, group) base / from the LDS slab; -1: column outside the image or no unit
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = tid + SQW_T * k;
+        const bool in = i < NROW * nq;
+        const int c = in ? i / nq : 0, q = in ? i - c * nq : 0;
+        const int ww = w0 + c - 1;
+        src_off[k] = (in && ww >= 0 && ww < W) ? ww * D + 4 * q : -1;
+        dst_off[k] = in ? c * DS + 4 + 4 * q : -1;
+    }
+    const long row_floats = (long)W * D;
+    auto fetch = [&](int r, int g, float4 (&st)[NL]) {
+        const float* base = geo + (((long)b * G + g) * H + r) * row_floats;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(base + max(src_off[k], 0));
+            st[k] = src_off[k] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int parity, const float4 (&st)[NL]) {
+        float* buf = sm + parity * SLAB;
+#pragma unroll
+        for (int k = 0; k < NL; ++k)
+            if (dst_off[k] >= 0) *reinterpret_cast<float4*>(buf + dst_off[k]) = st[k];
+    };
+    for (int i = tid; i < 2 * (NROW + 1); i += SQW_T) {  // the pads: candidates -1 and D of every slab row
+        float* pad = sm + (i / (NROW + 1)) * SLAB + (i % (NROW + 1)) * DS;
+        pad[0] = pad[1] = pad[2] = pad[3] = 0.f;
+    }
+    int fr = rlo, fg = 0;  // (row, group) of the next slab to fetch
+    auto fetch_next = [&](float4 (&st)[NL]) {
+        fetch(fr, fg, st);
+        if (++fg == G) fg = 0, ++fr;
+    };
+#pragma unroll
+    for (int u = 0; u < SQW_P; ++u)
+        if (u < nslab) fetch_next(stage[u]);
+    commit(0, stage[0]);
+    if (SQW_P < nslab) fetch_next(stage[0]);
+    __syncthreads();
+    const int cols_off = (SQW_PXT * half) * DS + 3 + min(dl, D - 1);  // threads beyond D multiply a copy of the last candidate; not parked
+    int parked = 0, park_h = h0;  // rows waiting for their soft-argmin, the first of them
+    int r = rlo, g = 0;           // (row, group) of slab s
+    for (int s0 = 0; s0 < nslab; s0 += SQW_P) {
+#pragma unroll
+        for (int u = 0; u < SQW_P; ++u) {
+            const int s = s0 + u;  // buffer s & 1 = u & 1 holds it; ring slots u + 1 .. hold slabs s + 1 .., slot u slab s + SQW_P
+            if (s >= nslab) break;
+            const float* cols = sm + (u & 1) * SLAB + cols_off;
+            const float* wg = a.w + g * 27;
+            // rows whose three neighbours are not all in the band: the band's first / last input row feed one output row;
+            // its first / last own row (mask 6 / 3) takes the full walk, the set outside the band is never parked
+            const bool t0 = r - 1 >= h0 && r - 1 < hend, t1 = r >= h0 && r < hend, t2 = r + 1 >= h0 && r + 1 < hend;
+            if (t2 && !t0 && !t1) squeeze_walk_slab<4>(cols, DS, wg, acc);
+            else if (t0 && !t1 && !t2) squeeze_walk_slab<1>(cols, DS, wg, acc);
+            else squeeze_walk_slab<7>(cols, DS, wg, acc);
+            if (s + 1 < nslab) commit((u + 1) & 1, stage[(u + 1) % SQW_P]);
+            __syncthreads();
+            if (s + 1 + SQW_P < nslab) fetch_next(stage[(u + 1) % SQW_P]);
+            if (g == G - 1) {  // input row r is done: output row r - 1 is complete, and on the image's last row so is row r (no row H)
+                const int nfin = (r == H - 1 && r < hend) ? 2 : 1;
+                for (int f = 0; f < nfin; ++f) {
+                    const int h = r - 1 + f;
+                    if (h >= h0 && h < hend) {
+                        if (dl < D)
+#pragma unroll
+                            for (int p = 0; p < SQW_PXT; ++p) lg[(parked * SQ_PX + SQW_PXT * half + p) * DP + dl] = acc[0][p] + a.bias;
+                        ++parked;
+                    }
+#pragma unroll
+                    for (int p = 0; p < SQW_PXT; ++p) acc[0][p] = acc[1][p], acc[1][p] = acc[2][p], acc[2][p] = 0.f;
+                    if (parked == SQW_TB || (parked > 0 && h == hend - 1)) {
+                        squeeze_walk_softargmin(lg, DP, D, parked, out + ((long)b * H + park_h) * W, W, w0);
+                        park_h += parked;
+                        parked = 0;
+                        __syncthreads();  // the chains read lg to the end
+                    }
+                }
+            }
+            if (++g == G) g = 0, ++r;
+        }
     }
 }
 
@@ -1509,6 +1837,20 @@ int nnd_igev_init_disparity(const float* geo_level0, const float* weight, const 
     for (int i = 0; i < G * 27; ++i) a.w[i] = weight[i];
     for (int i = G * 27; i < SQ_MAXG * 27; ++i) a.w[i] = 0.f;
     a.bias = bias ? bias[0] : 0.f;
+    // the walking kernel, bands of 8 rows, when those fill the chip (2 workgroups of 512 per CU); smaller problems: measured slower
+    // than the one-row kernel (68x120x120: 68 vs 54 us with bands of 2 rows), which also takes D > 256 and D % 4 != 0
+    // (NND_IGEV_SQUEEZE_WALK: whenever it can run — the tests' small shapes)
+    if (D <= 256 && (D & 3) == 0 && !switches().igev_squeeze_v1 &&
+        ((long)cdiv(W, SQ_PX) * cdiv(H, 8) * B >= 384 || switches().igev_squeeze_walk)) {
+        const int R = 8;
+        const long nwg = (long)cdiv(W, SQ_PX) * cdiv(H, R) * B;
+        NND_REQUIRE(nwg < (1L << 30), "igev_init_disparity: grid too large");
+        const size_t lds_walk = sizeof(float) * ((size_t)2 * ((SQ_PX + 2) * (D + 4) + 4) + (size_t)SQW_TB * SQ_PX * (D + 4));
+        hipLaunchKernelGGL(igev_squeeze_walk_kernel, dim3((unsigned)(8 * cdiv64(nwg, 8))), dim3(SQW_T), lds_walk, (hipStream_t)stream,
+                           geo_level0, out, a, G, H, W, D, R, (int)nwg);
+        NND_LAUNCH_CHECK();
+        return NND_OK;
+    }
     const size_t lds = (size_t)3 * (SQ_PX + 2) * (D + 2) * sizeof(float);
     dim3 grid(cdiv(W, SQ_PX) * 8 * cdiv(H, 8), 1, B), block(256);  // 8 bands of ceil(H/8) rows, see the kernel
     if (D <= 256)

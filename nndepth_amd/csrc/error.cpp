@@ -23,6 +23,9 @@ static void load_switches() {
     s.agcl_v1 = on("NND_AGCL_V1");
     s.no_thin3d = on("NND_NO_THIN3D");
     s.corr_build_v1 = on("NND_CORR_BUILD_V1");
+    s.corr_build_no_ksplit = on("NND_CORR_BUILD_NO_KSPLIT");
+    s.igev_squeeze_v1 = on("NND_IGEV_SQUEEZE_V1");
+    s.igev_squeeze_walk = on("NND_IGEV_SQUEEZE_WALK");
     s.no_conv1x1_stream = on("NND_NO_CONV1X1_STREAM");
     s.conv_verbose = on("NND_CONV_VERBOSE");
     s.debug_sync = on("NND_DEBUG_SYNC");

@@ -118,7 +118,18 @@ def test_corr1d_edge_cases(ops, monkeypatch):
         monkeypatch.setenv("NND_CORR_BUILD_V1", "1")
         v1 = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
         monkeypatch.delenv("NND_CORR_BUILD_V1")
-        assert torch.equal(v1, pyr), (B, C, H, W)
+        # C >= 32 on a small grid runs the k-split kernel (4 partial sums per output, added in wave order): it is held to
+        # the oracle above; the LDS-staged kernel behind NND_CORR_BUILD_NO_KSPLIT is the one that equals v1 bit for bit
+        monkeypatch.setenv("NND_CORR_BUILD_NO_KSPLIT", "1")
+        staged = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
+        monkeypatch.delenv("NND_CORR_BUILD_NO_KSPLIT")
+        assert torch.equal(v1, staged), (B, C, H, W)
+        if C < 32:
+            assert torch.equal(v1, pyr), (B, C, H, W)
+        else:
+            assert not torch.equal(staged, pyr) and (staged - pyr).abs().max() <= 4e-6, (B, C, H, W)
+            again = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
+            assert torch.equal(again, pyr)  # fixed summation order: run-to-run identical
 
 
 # ------------------------------------------------------------------------------------ upsample
@@ -1005,20 +1016,41 @@ def test_igev_softargmin_vs_oracle(ops, R):
         assert (got - exp).abs().max() <= 2e-5 * D, (B, D, H, W)
 
 
-def test_igev_squeezer_init_vs_oracle(ops, R):
+def test_igev_squeezer_init_vs_oracle(ops, R, monkeypatch):
     """cv_squeezer Conv3d(G,1,3,1,1) + soft-argmin fused (nnd_igev_init_disparity) vs the PyTorch CPU ops of the reference
     (igev_stereo/model.py:144-146), incl. ragged widths, one candidate per thread and two (D > 256), G < 8, more image rows than XCD bands
-    (H = 17) and a single row."""
+    (H = 17), a single row, the row-walking kernel (D <= 256, D % 4 == 0; bands of 8 rows, ragged last bands, bands shorter than a
+    soft-argmin batch) forced on these small shapes, and the one-row kernel (D = 21, 7, 300 always)."""
     torch.manual_seed(14)
     for (B, G, H, W, D, amp) in ((2, 8, 9, 21, 21, 1.0), (1, 8, 5, 13, 300, 0.5), (1, 3, 4, 8, 7, 2.0), (1, 8, 3, 17, 240, 1.0),
-                                 (1, 8, 17, 10, 32, 1.0), (1, 8, 1, 9, 16, 1.0)):
+                                 (1, 8, 17, 10, 32, 1.0), (1, 8, 1, 9, 16, 1.0), (1, 4, 43, 100, 24, 1.0), (2, 2, 35, 250, 12, 1.0),
+                                 (1, 8, 19, 61, 256, 1.0)):
         geo = torch.randn(B, G, H, W, D) * amp
         conv = torch.nn.Conv3d(G, 1, 3, 1, 1)
         with torch.no_grad():
             exp = R.igev_init_disparity(conv(geo.permute(0, 1, 4, 2, 3)).squeeze(1))
             got = ops.igev_init_disparity(geo.to(DEV), conv.weight, conv.bias, B, G, H, W, D).cpu()
+            monkeypatch.setenv("NND_IGEV_SQUEEZE_V1", "1")
+            one_row = ops.igev_init_disparity(geo.to(DEV), conv.weight, conv.bias, B, G, H, W, D).cpu()
+            monkeypatch.delenv("NND_IGEV_SQUEEZE_V1")
+            monkeypatch.setenv("NND_IGEV_SQUEEZE_WALK", "1")  # the walking kernel below the size at which it is the default
+            walk = ops.igev_init_disparity(geo.to(DEV), conv.weight, conv.bias, B, G, H, W, D).cpu()
+            monkeypatch.delenv("NND_IGEV_SQUEEZE_WALK")
         assert got.shape == exp.shape
-        assert (got - exp).abs().max() <= 2e-5 * D, (B, G, H, W, D, float((got - exp).abs().max()))
+        for name, v in (("default", got), ("one-row", one_row), ("walk", walk)):
+            assert (v - exp).abs().max() <= 2e-5 * D, (name, B, G, H, W, D, float((v - exp).abs().max()))
+        if D <= 256 and D % 4 == 0:
+            assert not torch.equal(walk, one_row)  # two kernels, two summation orders of the Conv3d
+        else:
+            assert torch.equal(walk, one_row)
+    # the size at which the walking kernel is the default (bands of 8 rows fill the chip), against the one-row kernel
+    geo = torch.randn(1, 8, 100, 320, 64, device=DEV)
+    conv = torch.nn.Conv3d(8, 1, 3, 1, 1)
+    got = ops.igev_init_disparity(geo, conv.weight, conv.bias, 1, 8, 100, 320, 64)
+    monkeypatch.setenv("NND_IGEV_SQUEEZE_V1", "1")
+    one_row = ops.igev_init_disparity(geo, conv.weight, conv.bias, 1, 8, 100, 320, 64)
+    monkeypatch.delenv("NND_IGEV_SQUEEZE_V1")
+    assert not torch.equal(got, one_row) and (got - one_row).abs().max() <= 2e-5 * 64
 
 
 def test_igev_forward_golden(gold):
