@@ -1,6 +1,6 @@
 """HBM-bound kernels of the hot path at their BASELINE.json config shapes: time per call (events on the launch stream =
 torch's current stream) and achieved GB/s over the ALGORITHMIC bytes (nndepth_amd/profiling.py; bench.py reports the same
-rows live as roofline.hbm_group).      python scripts/prof_hbm.py [igev]     (on the GPU box)"""
+rows live as roofline.hbm_group).      python scripts/prof_hbm.py [igev|raft]     (on the GPU box)"""
 import os
 import sys
 
@@ -13,6 +13,8 @@ if __name__ == "__main__":
     dev = "cuda:0"
     if len(sys.argv) > 1 and sys.argv[1] == "igev":  # the IGEV group alone (scripts/pmc_hbm.sh)
         rows = profiling.igev_rows(dev)
+    elif len(sys.argv) > 1 and sys.argv[1] == "raft":  # the RAFT-Stereo group alone
+        rows = profiling.raft_rows(dev)
     else:
         rows = profiling.raft_rows(dev) + profiling.raft_rows(dev, B=8, H=48, W=156) + profiling.igev_rows(dev) + profiling.cre_rows(dev)
     print(profiling.format_rows(rows))
