@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NND_VERSION 102 /* 0.1.2: descriptors carry struct_size and flags; per-layer fp16x2 activation scales + calibration */
+#define NND_VERSION 103 /* 0.1.2: descriptors carry struct_size and flags; per-layer fp16x2 activation scales + calibration */
 
 /* Descriptors start with `struct_size` = sizeof(the descriptor type) of the header the caller was compiled against; every entry
  * point that takes one refuses another size (NND_ERR_INVALID), so a caller and a library of different versions cannot
@@ -104,6 +104,17 @@ int nnd_corr1d_lookup(const float* pyramid, const float* coords, float* out,
  * = i*2*G*T + v*G*T + g*T + k with v = 0 feature / 1 geometry volume.                                   */
 int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
                          int num_groups, int group_channels, int num_levels, void* stream);
+/* GroupCorrBlock1D of Coarse2FineGroupRepViTRAFTStereo (nndepth/models/raft_stereo/cost_volume.py:64-128; widening):
+ * nnd_group_corr_build_scaled = nnd_group_corr_build with the divisor given by the caller — GroupCorrBlock1D.corr (:115-128) splits the
+ * maps into chunks of `num_groups` channels, correlates the first `num_groups` chunks and divides by sqrt(C_total):
+ * group_channels = num_groups, divisor = sqrt(Ctot).
+ * nnd_group_corr1d_lookup = GroupCorrBlock1D.__call__ (:94-113) INCLUDING its view without the group permute (Q6): coords (B,1,H,W) ->
+ * out (B, num_levels*G*(2r+1), H, W); pixel (y,x), channel i*G*T + j holds sample j % T of row (y*W + x)*G + j/T of the sample's
+ * G*H*W (group, pixel) rows at level i, each row sampled at ITS OWN pixel's coordinate.                                        */
+int nnd_group_corr_build_scaled(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
+                                int num_groups, int group_channels, int num_levels, float divisor, void* stream);
+int nnd_group_corr1d_lookup(const float* pyramid, const float* coords, float* out, int B, int G, int H, int W, int num_levels,
+                            int radius, void* stream);
 int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels, void* stream);
 int nnd_igev_lookup(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out,
                     int B, int G, int H, int W, int num_levels, int radius, void* stream);
@@ -424,6 +435,14 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
                            const float* net, const float* inp, const float* disp_init,
                            float* up_out, int64_t up_iter_stride, float* low_out, float* net_out,
                            float* workspace, int B, int H, int W, int rate, int iters, void* stream);
+/* One cascade stage of Coarse2FineGroupRepViTRAFTStereo.forward (nndepth/models/raft_stereo/model.py:297-311): the same loop with
+ * nnd_group_corr1d_lookup over `group_pyramid` (nnd_group_corr_build_scaled); disp_init = the previous stage's up_disp (its
+ * resolution is this stage's: init_coords = org_coords + up_disp, :316).  The lookup runs as its own kernel (it gathers other
+ * pixels' rows, Q6), convc1 behind it; everything else as in nnd_raft_stereo_refine.                                            */
+int nnd_raft_stereo_group_refine(const nnd_update_block_desc* desc, const float* packed_dev, const float* group_pyramid, int num_groups,
+                                 int num_levels, int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
+                                 int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W, int rate,
+                                 int iters, void* stream);
 
 /* IGEV variant of the loop (nndepth/models/igev_stereo/model.py:148-158): lookup = nnd_igev_lookup over both
  * pyramids, and — reference quirk Q5 — the update block and the convex upsample receive the ABSOLUTE coordinate

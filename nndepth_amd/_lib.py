@@ -56,6 +56,8 @@ SIGNATURES = {
     "nnd_corr1d_build": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_corr1d_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_group_corr_build": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nnd_group_corr_build_scaled": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.c_float, _P]),
+    "nnd_group_corr1d_lookup": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_pyramid_from_level0": (_I, [_P, _I, _I, _I, _I, _P]),
     "nnd_igev_lookup": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nnd_softargmin_disparity": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -91,6 +93,8 @@ SIGNATURES = {
     "nnd_mask_upsample_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_raft_stereo_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
                                     _I, _I, _I, _I, _I, _P]),
+    "nnd_raft_stereo_group_refine": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P, _P,
+                                          _I, _I, _I, _I, _I, _P]),
     "nnd_igev_interleaved_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
     "nnd_igev_interleave_pyramids": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nnd_igev_interleave_level0_supported": (_I, [_I, _I, _I]),

@@ -36,6 +36,35 @@ class CorrBlock1D:
         return pyr[:B * H * W * W].view(B, H, W, W)
 
 
+class GroupCorrBlock1D:
+    """Drop-in for `GroupCorrBlock1D` (nndepth/models/raft_stereo/cost_volume.py:64-128; the correlation of
+    Coarse2FineGroupRepViTRAFTStereo): same constructor arguments, `corr_pyramid` (num_levels+1 entries shaped
+    (B*G*H*W, 1, W_l)) and `__call__(coords)`.  Both reference quirks are kept: only the first `num_groups` chunks of `num_groups`
+    channels are correlated, scaled by 1/sqrt(C_total) (Q4), and the lookup views its (B*G*H*W, 2r+1) samples as (B, H, W, -1)
+    without moving the group axis (Q6)."""
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4, num_groups: int = 4):
+        self.num_levels, self.radius, self.num_groups = num_levels, radius, num_groups
+        self.shape = tuple(fmap1.shape)
+        self._pyr = ops.raft_group_corr_build(fmap1.float(), fmap2.float(), num_groups, num_levels)
+
+    @property
+    def corr_pyramid(self) -> List[torch.Tensor]:
+        B, _, H, W = self.shape
+        rows = B * self.num_groups * H * W
+        offs, widths, _ = ops.pyramid_layout(B * self.num_groups, H, W, self.num_levels)
+        return [self._pyr[o:o + rows * w].view(rows, 1, w) for o, w in zip(offs, widths)]
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        return ops.group_corr1d_lookup(self._pyr, coords.float(), self.num_groups, self.num_levels, self.radius)
+
+    def corr(self, fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+        """Level 0 only, shaped (B, G, H, W1, W2) like the reference method."""
+        B, _, H, W = fmap1.shape
+        pyr = ops.raft_group_corr_build(fmap1.float(), fmap2.float(), self.num_groups, 1)
+        return pyr[:B * self.num_groups * H * W * W].view(B, self.num_groups, H, W, W)
+
+
 class GeometryAwareCostVolume:
     """Drop-in for IGEV's `GeometryAwareCostVolume` (nndepth/models/igev_stereo/cost_volume.py:9-98): same
     constructor arguments, `feat_corr_cv` / `geo_aware_cv` pyramid lists (num_levels+1 entries shaped

@@ -204,6 +204,8 @@ int thin3d_forward(int Cout, int C0, int C1, int stride, const float* packed, co
 // `tiled`: coords / sampled features (resp. flow / mask) are tile-major workspace tensors (layout.h), else NCHW
 int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int B, int H, int W, int num_levels,
                          int radius, hipStream_t stream, bool tiled);
+int group_lookup_flat_launch(const float* pyr, const float* coords, float* out, int B, int G, int H, int W, int num_levels, int radius,
+                             hipStream_t stream, bool tiled);
 int igev_lookup_launch(const float* feat_pyramid, const float* geo_pyramid, const float* coords, float* out, int B, int G, int H,
                        int W, int num_levels, int radius, hipStream_t stream, bool tiled);
 int convex_upsample_launch(const float* flow, const float* mask, float* out, int B, int C, int H, int W, int rate,

@@ -537,6 +537,54 @@ int corr1d_lookup_launch(const float* pyr, const float* coords, float* out, int 
     return NND_OK;
 }
 
+// GroupCorrBlock1D.__call__ (raft_stereo/cost_volume.py:94-113; the correlation of Coarse2FineGroupRepViTRAFTStereo), quirk Q6
+// included: per level the (B*G*H*W, 2r+1) samples — row (b,g,h,w) sampled at coords[b,h,w] / 2^i + dx — are VIEWED as
+// (B, H, W, G*(2r+1)) without moving the group axis, so output pixel (y, x), channel j of level i holds
+//   sample k = j % T of row r = (y*W + x)*G + j / T of batch b's G*H*W rows   (T = 2r+1; r -> (g', h', w') = (r / HW, r % HW / W, r % W)),
+// i.e. the samples of G consecutive (group, pixel) rows, usually of another pixel and group.  Output channel = i*G*T + j.
+// pyr: the group pyramid of nnd_group_corr_build(_scaled), rows ordered (b,g,h,w1).
+__global__ void __launch_bounds__(256) group_lookup_flat_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                                float* __restrict__ out, LookupArgs a, int G) {
+    const long HW = (long)a.H * a.W;
+    const int ntap = 2 * a.radius + 1, nch = a.num_levels * G * ntap;
+    const long total = (long)a.B * nch * HW;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long pix = idx % HW;
+    const int ch = (int)((idx / HW) % nch);
+    const int b = (int)(idx / (HW * nch));
+    const int lvl = ch / (G * ntap), j = ch - lvl * (G * ntap);
+    const long r = pix * G + j / ntap;  // row of the (g, h, w) enumeration whose samples land here
+    const int k = j % ntap;
+    const long spix = r % HW;           // its pixel: the coordinate it was sampled at
+    const int w2 = a.L.width[lvl];
+    const float* row = pyr + a.L.off[lvl] + ((long)b * G * HW + r) * w2;
+    const long so = pix_off(a.lay, (int)(spix / a.W), (int)(spix % a.W)), po = pix_off(a.lay, (int)(pix / a.W), (int)(pix % a.W));
+    float x = (float)(k - a.radius) + coords[(long)b * a.lay.plane + so] / (float)(1 << lvl);
+    const float wm1 = (float)(w2 - 1);
+    x = x / wm1;
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    x = x * wm1;
+    const float f0 = floorf(x), f1 = ceilf(x);
+    const float v0 = row[(int)f0], v1 = row[(int)f1];
+    const float coef = f1 - x;
+    out[((long)b * nch + ch) * a.lay.plane + po] = coef * v0 + (1.0f - coef) * v1;
+}
+
+int group_lookup_flat_launch(const float* pyr, const float* coords, float* out, int B, int G, int H, int W, int num_levels, int radius,
+                             hipStream_t stream, bool tiled) {
+    NND_REQUIRE(num_levels >= 1 && num_levels < MAX_LEVELS && G >= 1, "group lookup: num_levels %d / groups %d out of range", num_levels, G);
+    LookupArgs a;
+    make_layout(B * G, H, W, num_levels + 1, &a.L, nullptr);
+    a.B = B; a.H = H; a.W = W; a.num_levels = num_levels; a.radius = radius;
+    a.lay = make_lay(H, W, tiled);
+    NND_REQUIRE(a.L.width[num_levels - 1] >= 2, "group lookup: level %d has width %d < 2", num_levels - 1, a.L.width[num_levels - 1]);
+    const long total = (long)B * num_levels * G * (2 * radius + 1) * H * W;
+    hipLaunchKernelGGL(group_lookup_flat_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, stream, pyr, coords, out, a, G);
+    NND_LAUNCH_CHECK();
+    return NND_OK;
+}
+
 // relu(acc + bias) of one lane's pixel and 16 channels into c1: planar tile-major, or (out_c4) the 4-channel-interleaved
 // tile-major layout of layout.h, where registers 4q..4q+3 are one 16-B store
 // the lane's 16 bias values (accumulator register order), loaded by the callers BEFORE their MFMA loops: fetched inside the
@@ -1244,16 +1292,17 @@ int nnd_corr1d_build(const float* fmap1, const float* fmap2, float* pyramid, int
     return NND_OK;
 }
 
-int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
-                         int num_groups, int group_channels, int num_levels, void* stream) {
+int nnd_group_corr_build_scaled(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
+                                int num_groups, int group_channels, int num_levels, float divisor, void* stream) {
     NND_REQUIRE(fmap1 && fmap2 && pyramid, "group_corr_build: null pointer");
     NND_REQUIRE(B > 0 && H > 0 && W > 0 && num_groups > 0 && group_channels > 0 && num_groups * group_channels <= Ctot,
                 "group_corr_build: bad shape (groups %d x %d channels > %d)", num_groups, group_channels, Ctot);
     NND_REQUIRE(num_levels >= 0 && num_levels <= 5, "group_corr_build: 0..5 pooled levels");
+    NND_REQUIRE(divisor > 0.f, "group_corr_build: divisor must be positive");
     PyrLayout L;
     make_layout(B * num_groups, H, W, num_levels + 1, &L, nullptr);
     dim3 grid(cdiv(W, 32), H, B * num_groups), block(256);
-    float div = (float)sqrt((double)group_channels);
+    const float div = divisor;
     int rc_lds = NND_OK;
     if (corr1d_build_lds_launch(fmap1, fmap2, pyramid, L, group_channels, H, W, B, div, Ctot, num_groups, (hipStream_t)stream, &rc_lds)) {
         if (rc_lds != NND_OK) set_error("group_corr_build: launch failed");
@@ -1267,6 +1316,19 @@ int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid,
                            H, W, div, Ctot, num_groups);
     NND_LAUNCH_CHECK();
     return NND_OK;
+}
+
+int nnd_group_corr_build(const float* fmap1, const float* fmap2, float* pyramid, int B, int Ctot, int H, int W,
+                         int num_groups, int group_channels, int num_levels, void* stream) {
+    return nnd_group_corr_build_scaled(fmap1, fmap2, pyramid, B, Ctot, H, W, num_groups, group_channels, num_levels,
+                                       group_channels > 0 ? (float)sqrt((double)group_channels) : 1.f, stream);
+}
+
+int nnd_group_corr1d_lookup(const float* pyramid, const float* coords, float* out, int B, int G, int H, int W, int num_levels,
+                            int radius, void* stream) {
+    NND_REQUIRE(pyramid && coords && out, "group_corr1d_lookup: null pointer");
+    NND_REQUIRE(B > 0 && G > 0 && H > 0 && W > 0 && radius >= 0, "group_corr1d_lookup: bad shape");
+    return group_lookup_flat_launch(pyramid, coords, out, B, G, H, W, num_levels, radius, (hipStream_t)stream, false);
 }
 
 int nnd_pyramid_from_level0(float* pyramid, int B, int H, int W, int num_levels, void* stream) {

@@ -768,7 +768,8 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
                           int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
                           int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W,
                           int rate, int iters, void* stream, const float* geo_pyramid = nullptr, int groups = 1,
-                          const CreArgs* cre = nullptr, const float* interleaved = nullptr) {
+                          const CreArgs* cre = nullptr, const float* interleaved = nullptr, int flat_groups = 0) {
+    // flat_groups > 0: GroupCorrBlock1D's lookup (Coarse2Fine RAFT-Stereo): `pyramid` holds flat_groups group volumes per sample
     Plan p;
     int rc = make_plan(desc, &p);
     if (rc != NND_OK) return rc;
@@ -783,8 +784,9 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
                     (long long)cre->warped_floats);
     } else {
         NND_REQUIRE(fc == 1, "raft_stereo_refine: flow_channels must be 1");
-        NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1) * (igev ? 2 * groups : 1),
-                    "refine: cor_planes %d does not match levels*(2r+1)%s", p.d.cor_planes, igev ? "*2*groups" : "");
+        NND_REQUIRE(p.d.cor_planes == num_levels * (2 * radius + 1) * (igev ? 2 * groups : (flat_groups > 0 ? flat_groups : 1)),
+                    "refine: cor_planes %d does not match levels*(2r+1)%s", p.d.cor_planes, igev ? "*2*groups" : (flat_groups > 0 ? "*groups" : ""));
+        NND_REQUIRE(!(igev && flat_groups > 0), "refine: the IGEV and the group-RAFT lookups exclude each other");
     }
 
     NND_REQUIRE(p.d.mask_channels == 9 * rate * rate, "raft_stereo_refine: mask_channels %d != 9*rate^2", p.d.mask_channels);
@@ -832,6 +834,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             return agcl_iter_launch(cre->f1, cre->f2, w.flow, cre->warped, w.corr, B, cre->C, H, W, it & 1, st_, true);
         }
         if (igev) return igev_lookup_launch(pyramid, geo_pyramid, w.coords, w.corr, B, groups, H, W, num_levels, radius, st_, true);
+        if (flat_groups > 0) return group_lookup_flat_launch(pyramid, w.coords, w.corr, B, flat_groups, H, W, num_levels, radius, st_, true);
         return corr1d_lookup_launch(pyramid, w.coords, w.corr, B, H, W, num_levels, radius, st_, true);
     };
     // per-pair context terms of the GRU convs (inp is constant over the iterations)
@@ -851,7 +854,7 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_up = switches().no_fused_upsample;  // the parity tests toggle these (nnd_reload_switches)
     const bool no_fuse_lk = switches().no_fused_lookup;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
-    const bool fused_lk = !cre && !no_fuse_lk;
+    const bool fused_lk = !cre && !no_fuse_lk && flat_groups == 0;  // (the group-RAFT lookup gathers other pixels' rows: stand-alone kernel)
     const bool merged_fbl = fused_lk && !igev && !switches().no_merged_fb_lookup && !switches().no_fused_flow_branch &&
                             flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith);
     // a conv of the recurrence on the caller's stream (bracketed by timing events when nnd_profile_loop_conv asks for it)
@@ -1003,6 +1006,15 @@ int nnd_raft_stereo_refine(const nnd_update_block_desc* desc, const float* packe
     //  2x slower for a multi-stream DAG on ROCm 7.2 — see the schedule note in enqueue_refine.)
     return enqueue_refine(desc, packed, pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out,
                           net_out, workspace, B, H, W, rate, iters, stream);
+}
+
+int nnd_raft_stereo_group_refine(const nnd_update_block_desc* desc, const float* packed, const float* group_pyramid, int num_groups,
+                                 int num_levels, int radius, const float* net, const float* inp, const float* disp_init, float* up_out,
+                                 int64_t up_iter_stride, float* low_out, float* net_out, float* workspace, int B, int H, int W, int rate,
+                                 int iters, void* stream) {
+    NND_REQUIRE(num_groups > 0, "raft_stereo_group_refine: num_groups must be positive");
+    return enqueue_refine(desc, packed, group_pyramid, num_levels, radius, net, inp, disp_init, up_out, up_iter_stride, low_out, net_out,
+                          workspace, B, H, W, rate, iters, stream, nullptr, 1, nullptr, nullptr, num_groups);
 }
 
 int nnd_igev_refine_reads_interleaved(int num_groups, int num_levels, int radius) {

@@ -447,6 +447,35 @@ class UpdateBlockEngine:
                                              _p(ws), B, H, W, rate, iters, _stream(d)), "raft_stereo_refine")
         return up, low, net_out
 
+    def refine_group(self, group_pyr, num_groups: int, num_levels: int, radius: int, net, inp, rate: int, iters: int,
+                     disp_init=None, keep_all: bool = True):
+        """One cascade stage of Coarse2FineGroupRepViTRAFTStereo (raft_stereo/model.py:297-311): refine() with GroupCorrBlock1D's
+        lookup over the pyramid of raft_group_corr_build -> (up, low, net)."""
+        if self.packed is None:
+            raise NndError("UpdateBlockEngine: parameters not loaded")
+        d = _dev(group_pyr, net, inp, self.packed)
+        net, inp = net.contiguous(), inp.contiguous()
+        B, _, H, W = net.shape
+        self._check_state("refine_group", net, inp, disp_init, 1)
+        need = pyramid_layout(B * num_groups, H, W, num_levels)[2]
+        if group_pyr.numel() != need:
+            raise NndError(f"refine_group: pyramid holds {group_pyr.numel()} floats, expected {need} for B*G={B * num_groups}, "
+                           f"{H}x{W}, {num_levels} levels")
+        n_up = iters if keep_all else 1
+        up = torch.empty((n_up, B, 1, rate * H, rate * W), dtype=torch.float32, device=d)
+        low = torch.empty((B, 1, H, W), dtype=torch.float32, device=d)
+        net_out = torch.empty_like(net)
+        ws = self.workspace(B, H, W, d)
+        stride = up[0].numel() if keep_all else 0
+        if disp_init is not None:
+            _dev(disp_init)
+            disp_init = disp_init.contiguous()
+        with torch.cuda.device(d):
+            check(lib.nnd_raft_stereo_group_refine(self._desc(), _p(self.packed), _p(group_pyr), num_groups, num_levels, radius,
+                                                   _p(net), _p(inp), _p(disp_init), _p(up), stride, _p(low), _p(net_out),
+                                                   _p(ws), B, H, W, rate, iters, _stream(d)), "raft_stereo_group_refine")
+        return up, low, net_out
+
     def refine_igev(self, feat_pyr, geo_pyr, num_groups: int, num_levels: int, radius: int, net, inp, rate: int,
                     iters: int, disp_init=None, keep_all: bool = True, interleaved=None):
         """IGEV loop (absolute coordinates, combined lookup) -> (up, low, net) like refine().
@@ -568,6 +597,42 @@ def group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, 
         check(lib.nnd_group_corr_build(_p(fmap1), _p(fmap2), _p(pyr), B, Ctot, H, W, num_groups, group_channels,
                                        num_levels if pooled else 0, _stream(d)), "group_corr_build")
     return pyr
+
+
+def raft_group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, num_levels: int) -> torch.Tensor:
+    """GroupCorrBlock1D.corr + pyramid (raft_stereo/cost_volume.py:84-92,115-128): the first num_groups chunks of num_groups channels,
+    divided by sqrt(C_total) (Q4); rows ordered (b,g,h,w1); layout = pyramid_layout(B*num_groups, H, W, num_levels)."""
+    d = _dev(fmap1, fmap2)
+    fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+    B, Ctot, H, W = fmap1.shape
+    if num_groups * num_groups > Ctot:
+        raise NndError(f"raft_group_corr_build: {num_groups} chunks of {num_groups} channels exceed the {Ctot} channels of the maps")
+    _, _, total = pyramid_layout(B * num_groups, H, W, num_levels)
+    pyr = torch.empty(total, dtype=torch.float32, device=d)
+    with torch.cuda.device(d):
+        check(lib.nnd_group_corr_build_scaled(_p(fmap1), _p(fmap2), _p(pyr), B, Ctot, H, W, num_groups, num_groups, num_levels,
+                                              float(Ctot) ** 0.5, _stream(d)), "group_corr_build_scaled")
+    return pyr
+
+
+def group_corr1d_lookup(pyr: torch.Tensor, coords: torch.Tensor, num_groups: int, num_levels: int, radius: int) -> torch.Tensor:
+    """GroupCorrBlock1D.__call__ (raft_stereo/cost_volume.py:94-113, view without the group permute included) ->
+    (B, num_levels*num_groups*(2r+1), H, W)."""
+    d = _dev(pyr, coords)
+    coords = coords.contiguous()
+    B, one, H, W = coords.shape
+    if one != 1:
+        raise NndError("group_corr1d_lookup: coords must be (B,1,H,W)")
+    if pyr.numel() != pyramid_layout(B * num_groups, H, W, num_levels)[2]:
+        raise NndError(f"group_corr1d_lookup: pyramid holds {pyr.numel()} floats, expected "
+                       f"{pyramid_layout(B * num_groups, H, W, num_levels)[2]} for B*G={B * num_groups}, {H}x{W}, {num_levels} levels")
+    out = torch.empty((B, num_levels * num_groups * (2 * radius + 1), H, W), dtype=torch.float32, device=d)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(d):
+        check(lib.nnd_group_corr1d_lookup(_p(pyr), _p(coords), _p(out), B, num_groups, H, W, num_levels, radius, _stream(d)),
+              "group_corr1d_lookup")
+    return out
 
 
 def pyramid_from_level0(level0: torch.Tensor, B: int, H: int, W: int, num_levels: int) -> torch.Tensor:

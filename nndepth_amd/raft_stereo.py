@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import NndError
 from .blocks import BasicUpdateBlock
-from .cost_volume import CorrBlock1D
+from .cost_volume import CorrBlock1D, GroupCorrBlock1D
 from .encoder import BasicEncoder
 from .upsample import convex_upsample
 
@@ -182,6 +182,131 @@ class BaseRAFTStereo(AutoCalibrate, nn.Module):
             coords1 = coords1 + delta
             outs.append({"up_disp": self.convex_upsample(coords1 - org, mask, rate=rate)})
         return outs
+
+
+class Coarse2FineRAFTStereoBase(AutoCalibrate, nn.Module):
+    """The hot path of `Coarse2FineGroupRepViTRAFTStereo` (nndepth/models/raft_stereo/model.py:166-320) on HIP: per cascade stage the
+    group correlation pyramid (GroupCorrBlock1D, quirks Q4 / Q6 kept), the ConvGRU update block (`gru="conv_gru"`, spatial scale
+    (4, 4)), the convex upsample and the loop around them, stage after stage (1/64 -> 1/16 -> 1/4 with the reference's encoder), every
+    iteration's disparity brought to frame size like the reference (`interpolate` x rate, nearest).
+
+    The encoder side is NOT part of the path (the RepViT backbone, the MobileOne `cnet_proj` and the FeatureFusionBlocks
+    are PyTorch modules in the reference and stay PyTorch-ROCm modules here): a subclass supplies them through `_init_fnet`,
+    `_init_cnet_proj`, `_init_fusion_blocks` with the reference's interfaces — `fnet(x)` returns the feature pyramid of which
+    `[::2][::-1]` are the stages, `cnet_proj[idx](fmap1)` -> (B, 2 * context_dim, H, W), split in halves into net / inp,
+    `fusion_blocks[idx-1]([previous_feat, feat])` —, or `patch_coarse2fine(model)` adopts them from a reference instance."""
+
+    def __init__(self, iters: int = 12, hidden_dim: int = 128, context_dim: int = 128, corr_levels: int = 1, corr_radius: int = 4,
+                 num_groups: int = 4, weights: Optional[str] = None, strict_load: bool = True, fused_loop: bool = True,
+                 arithmetic: str = "fp16x2", **kwargs):
+        super().__init__()
+        assert corr_levels == 1, "Corr level must be 1 in Coarse2FineGroupRepViTRaftStereo"  # model.py:214
+        self.arithmetic = arithmetic
+        self.iters, self.hidden_dim, self.context_dim = iters, hidden_dim, context_dim
+        self.corr_levels, self.corr_radius, self.num_groups = corr_levels, corr_radius, num_groups
+        self.fused_loop = fused_loop
+        self.fnet = self._init_fnet()
+        self.cnet_proj = self._init_cnet_proj()
+        self.fusion_blocks = self._init_fusion_blocks()
+        self.update_block = BasicUpdateBlock(hidden_dim=hidden_dim, cor_planes=num_groups * corr_levels * (2 * corr_radius + 1),
+                                             flow_channel=1, context_dim=context_dim, gru="conv_gru", spatial_scale=(4, 4),
+                                             arithmetic=arithmetic)
+        self.corr_fn = GroupCorrBlock1D
+        self.weights, self.strict_load = weights, strict_load
+        if weights is not None:
+            load_weights(self, weights, strict_load)
+
+    def _init_fnet(self) -> nn.Module:
+        raise NotImplementedError("Coarse2FineRAFTStereoBase: supply the encoder (reference: nndepth.encoders.rep_vit.RepViT)")
+
+    def _init_cnet_proj(self) -> nn.ModuleList:
+        raise NotImplementedError("Coarse2FineRAFTStereoBase: supply cnet_proj (reference: three 1x1 MobileOneBlocks, model.py:216-222)")
+
+    def _init_fusion_blocks(self) -> nn.ModuleList:
+        raise NotImplementedError("Coarse2FineRAFTStereoBase: supply fusion_blocks (reference: two FeatureFusionBlocks, model.py:223-228)")
+
+    def convex_upsample(self, flow, mask, rate=(4, 4)):
+        rate = rate if isinstance(rate, int) else rate[0]
+        return convex_upsample(flow, mask, rate)
+
+    def initialize_coords(self, fmap1):
+        B, _, H, W = fmap1.shape
+        return torch.arange(W, device=fmap1.device).float()[None, None, None, :].repeat(B, 1, H, 1)
+
+    def forward_features(self, frame1: torch.Tensor, frame2: torch.Tensor):
+        """Encoder side (PyTorch-ROCm): per stage the fused feature map of both frames (2B, C, H, W) and cnet (model.py:275-288)."""
+        B = frame1.shape[0]
+        features = self.fnet(torch.cat([frame1, frame2], dim=0))[::2][::-1]
+        feats, cnets, previous = [], [], None
+        for idx, feat in enumerate(features):
+            if previous is not None:
+                feat = self.fusion_blocks[idx - 1]([previous, feat])
+            feats.append(feat)
+            cnets.append(self.cnet_proj[idx](feat[:B].clone()))
+            previous = feat
+        return feats, cnets
+
+    def forward(self, frame1: torch.Tensor, frame2: torch.Tensor, **kwargs) -> List[Dict[str, torch.Tensor]]:
+        require_eval(self)
+        with torch.no_grad():
+            return self._forward_calibrated(frame1, frame2)
+
+    def _forward(self, frame1: torch.Tensor, frame2: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
+        feats, cnets = self.forward_features(frame1, frame2)
+        return self.refine_stages(feats, cnets, tuple(frame1.shape[-2:]))
+
+    def refine_stages(self, feats, cnets, frame_hw) -> List[Dict[str, torch.Tensor]]:
+        """The cascade behind the encoder side (model.py:280-320): HIP kernels only."""
+        B = feats[0].shape[0] // 2
+        outs: List[Dict[str, torch.Tensor]] = []
+        up_last = None
+        for idx, feat in enumerate(feats):
+            fmap1, fmap2 = feat[:B].float().contiguous(), feat[B:].float().contiguous()
+            cnet = cnets[idx].float()
+            net, inp = ops.split_tanh_relu(cnet, cnet.shape[1] // 2)
+            corr = self.corr_fn(fmap1, fmap2, self.corr_levels, self.corr_radius, self.num_groups)
+            if up_last is not None and tuple(up_last.shape[-2:]) != tuple(fmap1.shape[-2:]):
+                raise NndError(f"Coarse2FineRAFTStereoBase: stage {idx} is {tuple(fmap1.shape[-2:])} but the previous stage's "
+                               f"upsampled disparity is {tuple(up_last.shape[-2:])} (frame size not divisible by the pyramid's strides)")
+            if self.fused_loop and isinstance(corr, GroupCorrBlock1D):
+                eng = self.update_block.sync_engine(fmap1.device)
+                up, _, _ = eng.refine_group(corr._pyr, self.num_groups, self.corr_levels, self.corr_radius, net, inp, 4, self.iters,
+                                            disp_init=up_last, keep_all=True)
+                ups = [up[i] for i in range(self.iters)]
+            else:  # seam-by-seam loop (same shape as the reference's), every step still a HIP kernel
+                org = self.initialize_coords(fmap1)
+                coords1 = org if up_last is None else org + up_last
+                ups = []
+                for _ in range(self.iters):
+                    sampled = corr(coords1)
+                    net, mask, delta = self.update_block(net, inp, sampled, coords1 - org)
+                    coords1 = coords1 + delta
+                    ups.append(self.convex_upsample(coords1 - org, mask, rate=(4, 4)))
+            for u in ups:
+                rate = frame_hw[1] / u.shape[-1]
+                outs.append({"up_disp": u if rate == 1 else nn.functional.interpolate(u, size=tuple(frame_hw)) * rate})
+            up_last = ups[-1]
+        return outs
+
+
+def patch_coarse2fine(model: nn.Module, arithmetic: str = "fp16x2", fused_loop: bool = True) -> nn.Module:
+    """Swap the HIP hot path into a reference `Coarse2FineGroupRepViTRAFTStereo` instance in place: `patch()` for `update_block` and
+    `convex_upsample`, `corr_fn` = GroupCorrBlock1D, and `forward` = the reference's encoder side (its own fnet / fusion_blocks /
+    cnet_proj modules) followed by Coarse2FineRAFTStereoBase.refine_stages."""
+    patch(model, arithmetic)
+    model.corr_fn = GroupCorrBlock1D
+    model.convex_upsample = lambda flow, mask, rate=(4, 4): convex_upsample(flow, mask, rate if isinstance(rate, int) else rate[0])
+    model.arithmetic, model.fused_loop = arithmetic, fused_loop
+    cls = Coarse2FineRAFTStereoBase
+
+    def forward(frame1, frame2, **kwargs):
+        require_eval(model)
+        with torch.no_grad():
+            feats, cnets = cls.forward_features(model, frame1, frame2)
+            return cls.refine_stages(model, feats, cnets, tuple(frame1.shape[-2:]))
+
+    model.forward = forward
+    return model
 
 
 STEREO_MODELS = {"base-raft-stereo": BaseRAFTStereo}

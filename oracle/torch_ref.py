@@ -129,6 +129,73 @@ def igev_lookup(fp, gp, coords: torch.Tensor, num_groups: int, num_levels: int, 
     return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
 
 
+# ------------------------------------------- GroupCorrBlock1D (Coarse2FineGroupRepViTRAFTStereo)
+def raft_group_corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, num_groups: int, num_levels: int) -> List[torch.Tensor]:
+    """nndepth/models/raft_stereo/cost_volume.py:84-92,115-128: chunks of `num_groups` channels, the first `num_groups` chunks,
+    each divided by sqrt(C_TOTAL) (Q4) -> num_levels+1 tensors (B*G*H*W1, 1, W2_l), rows ordered (b,g,h,w1)."""
+    C = fmap1.shape[1]
+    g1 = torch.split(fmap1, num_groups, dim=1)
+    g2 = torch.split(fmap2, num_groups, dim=1)
+    vols = []
+    for i in range(num_groups):
+        a, b = g1[i].permute(0, 2, 3, 1), g2[i].permute(0, 2, 1, 3)
+        vols.append(torch.matmul(a, b) / C ** 0.5)
+    corr = torch.stack(vols, dim=1)
+    B, G, H, W1, W2 = corr.shape
+    corr = corr.reshape(B * G * H * W1, 1, W2)
+    pyr = [corr]
+    for _ in range(num_levels):
+        corr = F.avg_pool1d(corr, 2)
+        pyr.append(corr)
+    return pyr
+
+
+def raft_group_corr_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, num_groups: int, num_levels: int, radius: int) -> torch.Tensor:
+    """nndepth/models/raft_stereo/cost_volume.py:94-113.  The (B*G*H*W, 2r+1) samples are viewed as (B, H, W, -1) WITHOUT moving the
+    group axis (Q6): kept as is.  coords (B,1,H,W) -> (B, L*G*(2r+1), H, W)."""
+    B, _, H, W = coords.shape
+    outs = []
+    dx = torch.linspace(-radius, radius, 2 * radius + 1).view(1, -1)
+    for i in range(num_levels):
+        row = pyr[i].reshape(B * num_groups * H * W, -1)
+        c = coords.permute(0, 2, 3, 1).unsqueeze(1).repeat(1, num_groups, 1, 1, 1)
+        x = dx + c.reshape(B * num_groups * H * W, 1) / 2 ** i
+        outs.append(linear_sampler(row, x).view(B, H, W, -1))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+def coarse2fine_refine(sd: SD, feats: Sequence[torch.Tensor], cnets: Sequence[torch.Tensor], frame_hw, iters: int, num_groups: int = 4,
+                       corr_levels: int = 1, corr_radius: int = 4):
+    """The cascade of Coarse2FineGroupRepViTRAFTStereo.forward (nndepth/models/raft_stereo/model.py:272-320) behind its encoder side:
+    feats[idx] = the (fused) feature map of stage idx for both frames, (2B, C, H_idx, W_idx); cnets[idx] = cnet_proj[idx](fmap1).
+    Update block: conv_gru, spatial_scale (4, 4).  -> list of up_disp at frame size (len = stages * iters)."""
+    B = feats[0].shape[0] // 2
+    H0, W0 = feats[0].shape[-2:]
+    org = torch.arange(W0).float()[None, None, None, :].repeat(B, 1, H0, 1)
+    init = org.clone()
+    outs = []
+    up = None
+    for idx, feat in enumerate(feats):
+        fmap1, fmap2 = torch.split(feat, [B, B], dim=0)
+        cnet = cnets[idx]
+        net, inp = torch.split(cnet, cnet.shape[1] // 2, dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+        pyr = raft_group_corr_build(fmap1.float(), fmap2.float(), num_groups, corr_levels)
+        coords1 = init
+        for _ in range(iters):
+            samp = raft_group_corr_lookup(pyr, coords1, num_groups, corr_levels, corr_radius)
+            net, mask, delta = update_block(sd, "update_block", net, inp, samp, coords1 - org, gru="conv_gru")
+            coords1 = coords1 + delta
+            up = convex_upsample(coords1 - org, mask, 4)
+            rate = frame_hw[1] / up.shape[-1]
+            outs.append(up if rate == 1 else F.interpolate(up, size=tuple(frame_hw)) * rate)
+        if idx < len(feats) - 1:
+            Hn, Wn = feats[idx + 1].shape[-2:]
+            org = torch.arange(Wn).float()[None, None, None, :].repeat(B, 1, Hn, 1)
+            init = org + up
+    return outs
+
+
 # ------------------------------------------------------------------------- update block
 def motion_encoder(sd: SD, p: str, flow: torch.Tensor, corr: torch.Tensor) -> torch.Tensor:
     """nndepth/blocks/update_block.py:57-65."""

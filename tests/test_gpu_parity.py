@@ -1334,3 +1334,111 @@ def test_igev_regulariser_hip_golden(gold, name, B, H, W):
     assert torch.equal(geo_std.view(-1, W), cv.geo_aware_cv[0][:, 0])
     for lvl in range(1, 5):
         assert torch.equal(cv.geo_aware_cv[lvl], torch.nn.functional.avg_pool1d(cv.geo_aware_cv[lvl - 1], 2, stride=2))
+
+
+# --------------------------------------------- GroupCorrBlock1D / Coarse2Fine cascade (widening: raft_stereo/model.py:166-320)
+def test_raft_group_corr_golden(ops, gold, R):
+    """GroupCorrBlock1D (raft_stereo/cost_volume.py:64-128, Q4 / Q6 kept) against the reference class' fixtures: the build within fp32
+    accumulation order, the lookup on the reference's own pyramid bit for bit, the host class' reference-shaped views."""
+    from nndepth_amd.cost_volume import GroupCorrBlock1D
+    g = gold("c2f.npz")
+    for name in ("g4_c16_w20_l1", "g4_c64_w33_l2", "g2_c8_w12_l1_r2"):
+        B, C, H, W, L, r, G = (int(v) for v in g[name + "_cfg"])
+        f1, f2, coords = (t(g[f"{name}_{k}"]).to(DEV) for k in ("f1", "f2", "coords"))
+        offs, widths, total = ops.pyramid_layout(B * G, H, W, L)
+        rows = B * G * H * W
+        pyr = ops.raft_group_corr_build(f1, f2, G, L)
+        assert pyr.numel() == total
+        for i, (o, w) in enumerate(zip(offs, widths)):
+            ref = g[f"{name}_pyr{i}"].reshape(rows, w)
+            assert np.abs(pyr[o:o + rows * w].view(rows, w).cpu().numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (name, i)
+        flat = torch.zeros(total)
+        for i, (o, w) in enumerate(zip(offs, widths)):
+            flat[o:o + rows * w] = t(g[f"{name}_pyr{i}"]).reshape(-1)
+        out = ops.group_corr1d_lookup(flat.to(DEV), coords, G, L, r)
+        assert np.array_equal(out.cpu().numpy(), g[name + "_out"]), name  # the reference's pyramid in: bit-exact out
+        blk = GroupCorrBlock1D(f1, f2, L, r, G)
+        assert [tuple(p.shape) for p in blk.corr_pyramid] == [(rows, 1, w) for w in widths]
+        assert np.abs(blk(coords).cpu().numpy() - g[name + "_out"]).max() <= 2e-6 * max(1.0, np.abs(g[name + "_out"]).max())
+        assert tuple(blk.corr(f1, f2).shape) == (B, G, H, W, W)
+        with pytest.raises(Exception):
+            ops.group_corr1d_lookup(flat, coords.cpu(), G, L, r)  # CPU tensors are refused
+
+
+def test_raft_group_lookup_fullsize_vs_oracle(ops, R):
+    """Stage sizes of the cascade at 512x960 (8x15, 32x60, 128x240), batch 2, C = 256 / 64 / 64: build + lookup vs the oracle."""
+    torch.manual_seed(31)
+    for (C, H, W) in ((256, 8, 15), (64, 32, 60), (64, 128, 240)):
+        f1, f2 = torch.randn(2, C, H, W), torch.randn(2, C, H, W)
+        coords = torch.arange(W).float()[None, None, None, :].repeat(2, 1, H, 1) - torch.rand(2, 1, H, W) * 20
+        got = ops.group_corr1d_lookup(ops.raft_group_corr_build(f1.to(DEV), f2.to(DEV), 4, 1), coords.to(DEV), 4, 1, 4).cpu()
+        exp = R.raft_group_corr_lookup(R.raft_group_corr_build(f1, f2, 4, 1), coords, 4, 1, 4)
+        assert got.shape == exp.shape == (2, 36, H, W)
+        assert (got - exp).abs().max() <= 2e-6 * max(1.0, exp.abs().max().item()), (C, H, W)
+
+
+@pytest.mark.parametrize("arithmetic", ["fp32", "fp16x2", "bf16x3"])
+@pytest.mark.parametrize("name", ["c2f_b1_64x128_it3", "c2f_b2_128x192_it2"])
+def test_coarse2fine_cascade_golden(gold, name, arithmetic):
+    """The three-stage cascade of Coarse2FineGroupRepViTRAFTStereo.forward (group correlation, ConvGRU update block, convex upsample x4,
+    nearest resize to frame size, init of the next stage) on the stage tensors the reference's forward received, against its outputs:
+    fused loop (nnd_raft_stereo_group_refine) and seam-by-seam; then end to end through the test double's encoder side."""
+    from c2f_double import make_c2f
+    from nndepth_amd import weightgen
+    from nndepth_amd.raft_stereo import Coarse2FineRAFTStereoBase
+    g = gold("c2f.npz")
+    B, Hf, Wf, iters, seed = (int(v) for v in g[name + "_cfg"])
+    m = make_c2f(Coarse2FineRAFTStereoBase, iters=iters, corr_levels=1, arithmetic=arithmetic)
+    weightgen.fill_module_(m, "c2f.")
+    m = m.to(DEV).eval()
+    feats = [t(g[f"{name}_feat{i}"]).to(DEV) for i in range(3)]
+    cnets = [t(g[f"{name}_cnet{i}"]).to(DEV) for i in range(3)]
+    ref = g[name + "_ups"]
+    tol = 1.5e-5  # measured 1.7e-6 .. 6.9e-6 on disparities below 0.5 px (north_star: 1e-4)
+    errs = {}
+    for fused in (True, False):
+        m.fused_loop = fused
+        with torch.no_grad():
+            if arithmetic == "fp16x2":
+                with __import__("nndepth_amd").ops.calibration():
+                    m.refine_stages(feats, cnets, (Hf, Wf))
+            outs = m.refine_stages(feats, cnets, (Hf, Wf))
+        assert len(outs) == 3 * iters and all(tuple(o["up_disp"].shape) == (B, 1, Hf, Wf) for o in outs)
+        errs[fused] = max(np.abs(o["up_disp"].cpu().numpy() - ref[i]).max() for i, o in enumerate(outs))
+        assert errs[fused] <= tol, (name, arithmetic, fused, errs[fused])
+    m.fused_loop = True
+    f1, f2 = weightgen.synthetic_frames(seed, B, Hf, Wf)
+    out = m(f1.to(DEV), f2.to(DEV))
+    e2e = max(np.abs(o["up_disp"].cpu().numpy() - ref[i]).max() for i, o in enumerate(out))
+    print(f"{name} {arithmetic}: cascade fused {errs[True]:.2e} seam {errs[False]:.2e} end-to-end {e2e:.2e} (|up| max {np.abs(ref).max():.3f})")
+    assert e2e <= tol
+
+
+def test_patch_coarse2fine_equals_the_model_class():
+    """patch_coarse2fine on a reference-shaped instance (its own fnet / cnet_proj / fusion_blocks modules, a PyTorch update block) gives
+    the outputs of Coarse2FineRAFTStereoBase bit for bit."""
+    from c2f_double import make_c2f
+    from nndepth_amd import weightgen
+    from nndepth_amd.raft_stereo import Coarse2FineRAFTStereoBase, patch_coarse2fine
+    m = make_c2f(Coarse2FineRAFTStereoBase, iters=2, corr_levels=1, arithmetic="fp32")
+    weightgen.fill_module_(m, "c2f.")
+    m = m.to(DEV).eval()
+
+    class RefShaped(torch.nn.Module):  # what patch_coarse2fine needs of the reference class
+        pass
+
+    ref = RefShaped()
+    for k in ("fnet", "cnet_proj", "fusion_blocks", "update_block"):
+        setattr(ref, k, getattr(m, k))
+    for k in ("iters", "corr_levels", "corr_radius", "num_groups", "hidden_dim", "context_dim"):
+        setattr(ref, k, getattr(m, k))
+    ref = patch_coarse2fine(ref.eval(), arithmetic="fp32")
+    f1, f2 = weightgen.synthetic_frames(3, 1, 64, 128)
+    with torch.no_grad():
+        feats, cnets = m.forward_features(f1.to(DEV), f2.to(DEV))
+        a = m.refine_stages(feats, cnets, (64, 128))
+        b = Coarse2FineRAFTStereoBase.refine_stages(ref, feats, cnets, (64, 128))  # what the patched forward runs behind the encoder side
+    assert len(a) == len(b) == 6 and all(torch.equal(x["up_disp"], y["up_disp"]) for x, y in zip(a, b))
+    # end to end (the PyTorch-ROCm encoder side may pick another conv algorithm from call to call: not bit-stable)
+    c = ref(f1.to(DEV), f2.to(DEV))
+    assert len(c) == 6 and max((x["up_disp"] - y["up_disp"]).abs().max().item() for x, y in zip(a, c)) <= 1e-5
