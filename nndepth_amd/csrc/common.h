@@ -58,12 +58,13 @@ const Switches& switches();
 
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised on the device's copy of
 // the kernel: once per (call site = kernel instantiation, device).  `done` is the call site's own static bit mask over device ids.
-static inline int raise_lds_limit(const void* kern, std::atomic<unsigned>& done) {
+// (`bytes`: kernels that also declare static __shared__ arrays ask for less than the 160 KB: static + dynamic must fit)
+static inline int raise_lds_limit(const void* kern, std::atomic<unsigned>& done, int bytes = 160 * 1024) {
     int dev = 0;
     NND_HIP_CHECK(hipGetDevice(&dev));
     const unsigned bit = 1u << (dev & 31);
     if (!(done.load(std::memory_order_relaxed) & bit)) {
-        NND_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NND_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         done.fetch_or(bit, std::memory_order_relaxed);
     }
     return NND_OK;

@@ -1675,27 +1675,45 @@ __global__ void __launch_bounds__(256) igev_squeeze_softargmin_kernel(const floa
 // for SQW_TB rows at once (SQW_TB x SQ_PX sequential chains side by side instead of SQ_PX).  D <= 256, D % 4 == 0.
 // The sum over (g, kh, kw, kd) runs in the order (kh, g, column, kw, kd), one FMA per term, instead of (g, kh, column, kw,
 // [kd]) with the three kd terms added first: last-bit differences in the logits; the soft-argmin arithmetic is the same.
-constexpr int SQW_TB = 4, SQW_P = 4, SQW_T = 512, SQW_PXT = SQ_PX / 2;
-static_assert(SQW_P % 2 == 0, "the LDS buffer of a slab is its ring slot's parity");
-// one slab into the accumulators of a thread: candidate d, pixels p0 .. p0 + SQW_PXT - 1 of the strip (slab columns p0 .. p0 + SQW_PXT + 1)
+constexpr int SQW_TB = 4, SQW_T = 512, SQW_PXT = SQ_PX / 2;
+// one slab into the accumulators of a thread: candidate d, pixels p0 .. p0 + SQW_PXT - 1 of the strip (slab columns p0 .. p0 + SQW_PXT + 1).
+// Two pixels share a packed FMA: for the pixel pair (2j, 2j+1) and slab column c = 2j + e the taps are kw = e and e - 1, so the pair
+// takes (w1, w0) at e = 1 and (w2, w1) at e = 2 as ONE v_pk_fma_f32 with the candidate's value in both halves, and single FMAs at
+// e = 0 (w0, first pixel) and e = 3 (w2, second pixel).  The weight quads (w2, w1, w1, w0) of a (group, kh, kd) sit in LDS (wq:
+// [kh][kd]), one broadcast ds_read_b128 each: fetched from the kernel arguments the compiler rebuilt every pair with v_mov (50 of
+// the 104 VALU instructions of a slab) behind scalar loads issued at the top of every slab.  Per accumulator the terms arrive in the
+// order (column, kd) = the order of the scalar form: bit-identical logits.
+typedef float sq_f2 __attribute__((ext_vector_type(2)));
 template <int MASK>
-__device__ __forceinline__ void squeeze_walk_slab(const float* __restrict__ cols, int DS, const float* __restrict__ wg,
-                                                  float (&acc)[3][SQW_PXT]) {
+__device__ __forceinline__ void squeeze_walk_slab(const float* __restrict__ cols, int DS, const float4* __restrict__ wq,
+                                                  sq_f2 (&acc)[3][SQW_PXT / 2]) {
+    static_assert(SQW_PXT % 2 == 0, "pixel pairs");
+    float rr[SQW_PXT + 2][3];  // candidates d - 1, d, d + 1 of the slab columns p0 ..: read once, used by the three accumulator sets
 #pragma unroll
     for (int c = 0; c < SQW_PXT + 2; ++c) {
-        const float* row = cols + c * DS;  // candidate d - 1 of column p0 + c
-        const float r0 = row[0], r1 = row[1], r2 = row[2];
+        const float* row = cols + c * DS;
+        rr[c][0] = row[0], rr[c][1] = row[1], rr[c][2] = row[2];
+    }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (!((MASK >> t) & 1)) continue;
-            const int kh = 2 - t;  // accumulator set t belongs to output row r - 1 + t, which sees input row r as its kh = 2 - t
+    for (int t = 0; t < 3; ++t) {
+        if (!((MASK >> t) & 1)) continue;
+        float4 w[3];  // (w2, w1, w1, w0) per kd; set t sees this input row as its kh = 2 - t
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int p = c - kw;
-                if (p >= 0 && p < SQW_PXT) {
-                    acc[t][p] = fmaf(wg[0 * 9 + kh * 3 + kw], r0, acc[t][p]);
-                    acc[t][p] = fmaf(wg[1 * 9 + kh * 3 + kw], r1, acc[t][p]);
-                    acc[t][p] = fmaf(wg[2 * 9 + kh * 3 + kw], r2, acc[t][p]);
+        for (int kd = 0; kd < 3; ++kd) w[kd] = wq[(2 - t) * 3 + kd];
+#pragma unroll
+        for (int c = 0; c < SQW_PXT + 2; ++c) {
+#pragma unroll
+            for (int j = 0; j < SQW_PXT / 2; ++j) {
+                const int e = c - 2 * j;
+                if (e < 0 || e > 3) continue;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const float4 q = w[kd];
+                    const float r = rr[c][kd];
+                    if (e == 0) acc[t][j].x = fmaf(q.w, r, acc[t][j].x);
+                    else if (e == 1) acc[t][j] = __builtin_elementwise_fma(sq_f2{q.z, q.w}, sq_f2{r, r}, acc[t][j]);
+                    else if (e == 2) acc[t][j] = __builtin_elementwise_fma(sq_f2{q.x, q.y}, sq_f2{r, r}, acc[t][j]);
+                    else acc[t][j].y = fmaf(q.x, r, acc[t][j].y);
                 }
             }
         }
@@ -1769,7 +1787,8 @@ __device__ __forceinline__ void squeeze_walk_softargmin(float* lg, int DP, int D
     }
 }
 
-__global__ void __launch_bounds__(SQW_T) igev_squeeze_walk_kernel(const float* __restrict__ geo, float* __restrict__ out, SqueezeArgs a,
+template <int GS, int RP>
+__global__ void __launch_bounds__(SQW_T, 2) igev_squeeze_walk_kernel(const float* __restrict__ geo, float* __restrict__ out, SqueezeArgs a,
                                                                   int G, int H, int W, int D, int R, int nwg) {
     extern __shared__ float sm[];  // slabs [2][(SQ_PX + 2) * DS + 4], then the parked logits [SQW_TB * SQ_PX][DP]
     const int tid = threadIdx.x, dl = tid & 255, half = tid >> 8;  // thread: candidate dl, pixels 4 half .. 4 half + 3
@@ -1781,19 +1800,21 @@ __global__ void __launch_bounds__(SQW_T) igev_squeeze_walk_kernel(const float* _
     const int h0 = band * R, hend = min(h0 + R, H);
     // slab row c: [c * DS, c * DS + 4) pad (candidate -1 at +3), then D candidates; candidate D = the next row's first pad float
     constexpr int NROW = SQ_PX + 2, NL = (NROW * 64 + SQW_T - 1) / SQW_T;
-    const int DS = D + 4, nq = D >> 2, SLAB = NROW * DS + 4;
+    static_assert(RP % 2 == 0, "the LDS buffer of a slab is its ring slot's parity");
+    const int DS = D + 4, nq = D >> 2, SUB = NROW * DS + 4, SLAB = GS * SUB;  // a slab = GS groups of one input row (G % GS == 0)
     const int DP = ((D >> 2) & 1) ? D : D + 4;  // odd number of 16-byte units per parked row: the chains' b128 reads spread over the banks
     float* lg = sm + 2 * SLAB;
-    float acc[3][SQW_PXT];
+    float4* wl = reinterpret_cast<float4*>(lg + SQW_TB * SQ_PX * DP);  // [G][kh][kd] weight quads (w2, w1, w1, w0) over kw
+    sq_f2 acc[3][SQW_PXT / 2];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int p = 0; p < SQW_PXT; ++p) acc[t][p] = 0.f;
+        for (int j = 0; j < SQW_PXT / 2; ++j) acc[t][j] = sq_f2{0.f, 0.f};
     const int rlo = max(h0 - 1, 0), rhi = min(hend, H - 1);  // input rows that exist
-    const int nslab = (rhi - rlo + 1) * G;
-    // SQW_P slabs are on their way or parked in registers at any time; the register ring is indexed statically, so the slab
-    // loop is unrolled SQW_P times.  The 16-byte units of a thread: slab-invariant offsets.
-    float4 stage[SQW_P][NL];
+    const int nslab = (rhi - rlo + 1) * (G / GS);
+    // RP slabs are on their way or parked in registers at any time; the register ring is indexed statically, so the slab
+    // loop is unrolled RP times.  The 16-byte units of a thread: slab-invariant offsets.
+    float4 stage[RP][GS * NL];
     int src_off[NL], dst_off[NL];  // floats from the slab's (row, group) base / from the LDS slab; -1: column outside the image or no unit
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -1805,66 +1826,80 @@ __global__ void __launch_bounds__(SQW_T) igev_squeeze_walk_kernel(const float* _
         dst_off[k] = in ? c * DS + 4 + 4 * q : -1;
     }
     const long row_floats = (long)W * D;
-    auto fetch = [&](int r, int g, float4 (&st)[NL]) {
-        const float* base = geo + (((long)b * G + g) * H + r) * row_floats;
+    auto fetch = [&](int r, int g, float4 (&st)[GS * NL]) {
 #pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(base + max(src_off[k], 0));
-            st[k] = src_off[k] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int gs = 0; gs < GS; ++gs) {
+            const float* base = geo + (((long)b * G + g + gs) * H + r) * row_floats;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(base + max(src_off[k], 0));
+                st[gs * NL + k] = src_off[k] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
-    auto commit = [&](int parity, const float4 (&st)[NL]) {
+    auto commit = [&](int parity, const float4 (&st)[GS * NL]) {
         float* buf = sm + parity * SLAB;
 #pragma unroll
-        for (int k = 0; k < NL; ++k)
-            if (dst_off[k] >= 0) *reinterpret_cast<float4*>(buf + dst_off[k]) = st[k];
+        for (int gs = 0; gs < GS; ++gs)
+#pragma unroll
+            for (int k = 0; k < NL; ++k)
+                if (dst_off[k] >= 0) *reinterpret_cast<float4*>(buf + gs * SUB + dst_off[k]) = st[gs * NL + k];
     };
-    for (int i = tid; i < 2 * (NROW + 1); i += SQW_T) {  // the pads: candidates -1 and D of every slab row
-        float* pad = sm + (i / (NROW + 1)) * SLAB + (i % (NROW + 1)) * DS;
+    for (int i = tid; i < G * 9; i += SQW_T) {  // a.w is [g][kd][kh][kw]
+        const int g_ = i / 9, kh = (i % 9) / 3, kd = i % 3;
+        const float* w3 = a.w + g_ * 27 + kd * 9 + kh * 3;
+        wl[i] = make_float4(w3[2], w3[1], w3[1], w3[0]);
+    }
+    for (int i = tid; i < 2 * GS * (NROW + 1); i += SQW_T) {  // the pads: candidates -1 and D of every slab row
+        float* pad = sm + (i / (NROW + 1)) * SUB + (i % (NROW + 1)) * DS;
         pad[0] = pad[1] = pad[2] = pad[3] = 0.f;
     }
     int fr = rlo, fg = 0;  // (row, group) of the next slab to fetch
-    auto fetch_next = [&](float4 (&st)[NL]) {
+    auto fetch_next = [&](float4 (&st)[GS * NL]) {
         fetch(fr, fg, st);
-        if (++fg == G) fg = 0, ++fr;
+        if ((fg += GS) == G) fg = 0, ++fr;
     };
 #pragma unroll
-    for (int u = 0; u < SQW_P; ++u)
+    for (int u = 0; u < RP; ++u)
         if (u < nslab) fetch_next(stage[u]);
     commit(0, stage[0]);
-    if (SQW_P < nslab) fetch_next(stage[0]);
+    if (RP < nslab) fetch_next(stage[0]);
     __syncthreads();
     const int cols_off = (SQW_PXT * half) * DS + 3 + min(dl, D - 1);  // threads beyond D multiply a copy of the last candidate; not parked
     int parked = 0, park_h = h0;  // rows waiting for their soft-argmin, the first of them
     int r = rlo, g = 0;           // (row, group) of slab s
-    for (int s0 = 0; s0 < nslab; s0 += SQW_P) {
+    for (int s0 = 0; s0 < nslab; s0 += RP) {
 #pragma unroll
-        for (int u = 0; u < SQW_P; ++u) {
-            const int s = s0 + u;  // buffer s & 1 = u & 1 holds it; ring slots u + 1 .. hold slabs s + 1 .., slot u slab s + SQW_P
+        for (int u = 0; u < RP; ++u) {
+            const int s = s0 + u;  // buffer s & 1 = u & 1 holds it; ring slots u + 1 .. hold slabs s + 1 .., slot u slab s + RP
             if (s >= nslab) break;
             const float* cols = sm + (u & 1) * SLAB + cols_off;
-            const float* wg = a.w + g * 27;
             // rows whose three neighbours are not all in the band: the band's first / last input row feed one output row;
             // its first / last own row (mask 6 / 3) takes the full walk, the set outside the band is never parked
             const bool t0 = r - 1 >= h0 && r - 1 < hend, t1 = r >= h0 && r < hend, t2 = r + 1 >= h0 && r + 1 < hend;
-            if (t2 && !t0 && !t1) squeeze_walk_slab<4>(cols, DS, wg, acc);
-            else if (t0 && !t1 && !t2) squeeze_walk_slab<1>(cols, DS, wg, acc);
-            else squeeze_walk_slab<7>(cols, DS, wg, acc);
-            if (s + 1 < nslab) commit((u + 1) & 1, stage[(u + 1) % SQW_P]);
+#pragma unroll
+            for (int gs = 0; gs < GS; ++gs) {
+                const float4* wg = wl + (g + gs) * 9;
+                const float* cg = cols + gs * SUB;
+                if (t2 && !t0 && !t1) squeeze_walk_slab<4>(cg, DS, wg, acc);
+                else if (t0 && !t1 && !t2) squeeze_walk_slab<1>(cg, DS, wg, acc);
+                else squeeze_walk_slab<7>(cg, DS, wg, acc);
+            }
+            if (s + 1 < nslab) commit((u + 1) & 1, stage[(u + 1) % RP]);
             __syncthreads();
-            if (s + 1 + SQW_P < nslab) fetch_next(stage[(u + 1) % SQW_P]);
-            if (g == G - 1) {  // input row r is done: output row r - 1 is complete, and on the image's last row so is row r (no row H)
+            if (s + 1 + RP < nslab) fetch_next(stage[(u + 1) % RP]);
+            if (g + GS == G) {  // input row r is done: output row r - 1 is complete, and on the image's last row so is row r (no row H)
                 const int nfin = (r == H - 1 && r < hend) ? 2 : 1;
                 for (int f = 0; f < nfin; ++f) {
                     const int h = r - 1 + f;
                     if (h >= h0 && h < hend) {
                         if (dl < D)
 #pragma unroll
-                            for (int p = 0; p < SQW_PXT; ++p) lg[(parked * SQ_PX + SQW_PXT * half + p) * DP + dl] = acc[0][p] + a.bias;
+                            for (int p = 0; p < SQW_PXT; ++p) lg[(parked * SQ_PX + SQW_PXT * half + p) * DP + dl] = acc[0][p >> 1][p & 1] + a.bias;
                         ++parked;
                     }
 #pragma unroll
-                    for (int p = 0; p < SQW_PXT; ++p) acc[0][p] = acc[1][p], acc[1][p] = acc[2][p], acc[2][p] = 0.f;
+                    for (int j = 0; j < SQW_PXT / 2; ++j) acc[0][j] = acc[1][j], acc[1][j] = acc[2][j], acc[2][j] = sq_f2{0.f, 0.f};
                     if (parked == SQW_TB || (parked > 0 && h == hend - 1)) {
                         squeeze_walk_softargmin(lg, DP, D, parked, out + ((long)b * H + park_h) * W, W, w0);
                         park_h += parked;
@@ -1873,7 +1908,7 @@ __global__ void __launch_bounds__(SQW_T) igev_squeeze_walk_kernel(const float* _
                     }
                 }
             }
-            if (++g == G) g = 0, ++r;
+            if ((g += GS) == G) g = 0, ++r;
         }
     }
 }
@@ -1907,8 +1942,10 @@ int nnd_igev_init_disparity(const float* geo_level0, const float* weight, const 
         const int R = 8;
         const long nwg = (long)cdiv(W, SQ_PX) * cdiv(H, R) * B;
         NND_REQUIRE(nwg < (1L << 30), "igev_init_disparity: grid too large");
-        const size_t lds_walk = sizeof(float) * ((size_t)2 * ((SQ_PX + 2) * (D + 4) + 4) + (size_t)SQW_TB * SQ_PX * (D + 4));
-        hipLaunchKernelGGL(igev_squeeze_walk_kernel, dim3((unsigned)(8 * cdiv64(nwg, 8))), dim3(SQW_T), lds_walk, (hipStream_t)stream,
+        // one group per slab, 4 slabs in the register ring.  (Two groups per slab and a ring of 2 — half the barriers, the same bytes
+        // in flight, 72 KB of LDS — measured 158 us against 130: igev_squeeze_walk_kernel<2, 2> stays instantiable, not launched.)
+        const size_t lds_walk = sizeof(float) * ((size_t)2 * ((SQ_PX + 2) * (D + 4) + 4) + (size_t)SQW_TB * SQ_PX * (D + 4) + (size_t)SQ_MAXG * 9 * 4);
+        hipLaunchKernelGGL((igev_squeeze_walk_kernel<1, 4>), dim3((unsigned)(8 * cdiv64(nwg, 8))), dim3(SQW_T), lds_walk, (hipStream_t)stream,
                            geo_level0, out, a, G, H, W, D, R, (int)nwg);
         NND_LAUNCH_CHECK();
         return NND_OK;
