@@ -234,6 +234,12 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.nnd_softargmin_disparity(None, None, 1, 8, 4, 4, None) < 0
     assert lib.nnd_igev_init_disparity(None, None, None, None, 1, 8, 4, 4, 4, None) < 0
     assert lib.nnd_igev_interleave_pyramids(None, None, None, 1, 8, 4, 4, 4, None) < 0
+    # round 4 (GroupCorrBlock1D / Coarse2Fine cascade)
+    assert lib.nnd_group_corr_build_scaled(None, None, None, 1, 16, 4, 8, 4, 4, 1, 4.0, None) < 0
+    assert lib.nnd_group_corr1d_lookup(None, None, None, 1, 4, 4, 8, 1, 4, None) < 0
+    ug = UpdateBlockDesc(128, 128, 36, 1, 144, 1)
+    assert lib.nnd_raft_stereo_group_refine(C.byref(ug), None, None, 4, 1, 4, None, None, None, None, 0, None, None, None, 1, 4, 8, 4, 2,
+                                            None) < 0
     assert lib.nnd_igev_interleaved_floats(1, 8, 4, 8, 2) == 4 * 8 * (8 + 4) * 16
     d = ConvDesc(16, 16, 3, 3, 3)
     assert lib.nnd_conv_packed_floats(C.byref(d)) < 0 and b"stride" in lib.nnd_last_error()
