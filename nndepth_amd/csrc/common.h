@@ -40,7 +40,7 @@ void set_error(const char* fmt, ...);
 // loaded and again only by nnd_reload_switches(); the hot path never calls getenv.  They select between kernels that the parity
 // tests prove equivalent, never a non-HIP path.
 struct Switches {
-    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, corr_build_no_ksplit, igev_squeeze_v1, igev_squeeze_walk, no_conv1x1_stream,
+    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, corr_build_no_ksplit, igev_squeeze_v1, igev_squeeze_walk, no_folded_flow_head, mu_serial_fold, no_conv1x1_stream,
         conv_verbose, debug_sync;
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
@@ -234,8 +234,30 @@ int flow_branch_lookup_launch(const ConvLayer& f2, const float* blob, const floa
 bool igev_lookup_convc1_il_supported(int G, int num_levels, int radius);
 int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, const ConvLayer& L, const float* blob, float* c1,
                                  int64_t c1_bs, int B, int H, int W, int num_levels, int radius, hipStream_t stream, bool c1_c4);
+// flow_head.conv2 (3x3, hid -> 1) and the recurrence update of raft_stereo/model.py:134-135 folded into this kernel (round 4; fc == 1):
+// the workgroup needs the NEW flow on the 6x10 patch around its tile, so it computes delta = conv2(relu(conv1(h))) on those 60
+// positions itself — from the 8x12 patch of the flow head's hidden map, with flow_head2_kernel's arithmetic (16 slices of hid/16
+// channels x 9 taps with v_fmac_f32 each, summed in slice order, + bias: the same bits) — and adds it to the OLD coordinate.  Old
+// and new state live in two buffer pairs that the caller swaps every iteration (a neighbour workgroup may already have advanced
+// the pixels of this one's halo); the 32 pixels of the tile itself are written: new coordinate, new flow (also into the GRU's
+// input tensor) and delta.  Saves the flow_head2 launch (6.9 us + the gap behind it) for ~2 us in here.
+struct MaskUpFlowHead {
+    const float* x;       // flow head's hidden map relu(flow_head.conv1(h)): hid channels, layout `lay` / x_c4 of the mask input
+    long xbs;
+    int hid;
+    const float* w;       // (1, hid, 3, 3) and bias (1), as flow_head2_kernel reads them
+    const float* bias;
+    const float* coords_in;  // old state, (B,1,H,W) in `lay`
+    float *coords_out, *flow_out, *delta_out;
+    float* hx_flow;       // flow channel of the GRU input tensor
+    long hx_bs;
+    int hx_pm;            // floats between consecutive pixels there (4: c4)
+    int absolute;         // IGEV: the state handed on is the coordinate itself
+};
+
 bool mask_upsample_supported(int rate, int cin, int flow_channels);
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1, bool x_c4 = false);
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1, bool x_c4 = false,
+                         const MaskUpFlowHead* fh = nullptr);
 
 }  // namespace nnd

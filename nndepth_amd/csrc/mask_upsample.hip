@@ -19,6 +19,8 @@
 // softmax + store 3.2.  The x tile is staged as [16-ch chunk][piece][k half][pixel][8 bf16], so a B fragment is one
 // conflict-free ds_read_b128 per piece, shared by the wave's 3 output-channel blocks.
 #include "common.h"
+
+#include <type_traits>
 #include "layout.h"
 #include "split_arith.h"
 
@@ -47,6 +49,8 @@ struct MaskUpArgs {
     int H, W, tiles_x, fc;  // fc: flow channels, 1 (RAFT/IGEV disparity) or 2 (CREStereo flow)
     Lay lay;  // layout of x and flow (tile-major inside the loop, NCHW through the C-ABI)
     int x_c4;  // x keeps 4 channels interleaved (tile-major c4, layout.h); flow stays planar
+    int lds_floats;  // dynamic LDS of this launch; the flow patch sits in its last 128 floats
+    MaskUpFlowHead fh;  // fh.x != nullptr: flow_head.conv2 + the recurrence update run in this launch (below)
 };
 
 template <int RATE, int CIN>
@@ -63,8 +67,14 @@ struct MaskUpCfg {
     static constexpr int LDS_FLOATS = (XS_FLOATS > COUT * MT_STRIDE ? XS_FLOATS : COUT * MT_STRIDE) + 128;
 };
 
-template <int RATE, int CIN, int NS = 0>
-__global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kernel(MaskUpArgs a) {
+// FHW: extra waves (beyond the GEMM's NT threads) that run the folded flow head CONCURRENTLY with the staging and the K loop of the
+// mask GEMM — the flow head is a latency chain (hidden map from HBM -> 60 dot products -> new state) that nothing in the GEMM waits
+// for until the upsample reads the flow patch; its LDS lies behind the GEMM's.  The four barriers of the GEMM path (x tile staged |
+// K loop done | first K half in the mask tile | second) are the flow head's: patch staged | partial sums | new flow patch written |
+// (nothing).  FHW = 0 with fh.x set: the same work by all threads, serially in front of the x tile (the arithmetics whose GEMM waves
+// need more than 128 VGPRs, which 16 waves per CU do not leave).
+template <int RATE, int CIN, int NS = 0, int FHW = 0>
+__global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT + 64 * FHW)) mask_upsample_kernel(MaskUpArgs a) {
     constexpr bool SPLIT = NS != 0;
     using Cfg = MaskUpCfg<RATE, CIN>;
     constexpr int COUT = Cfg::COUT, NCB = Cfg::NCB, CBW = Cfg::CBW, G = Cfg::G, NT = Cfg::NT, NST = Cfg::NST;
@@ -76,7 +86,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     NND_MSTAMP(0);
     float* xs = lds;                          // [CIN][32]   (K loop)
     float* mt = lds;                          // [COUT][33]  (after the K loop; aliases xs)
-    float* fp = lds + Cfg::LDS_FLOATS - 128;  // [fc][6][10] flow patch, zero outside the image
+    float* fp = lds + a.lds_floats - 128;     // [fc][6][10] flow patch, zero outside the image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,27 +103,177 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
         xscale = a.bias[Cfg::NCB * 32 + SPLIT_TAIL_XSCALE];
     }
 
+    // ---- folded flow_head.conv2 + recurrence update (MaskUpFlowHead): the new flow patch.  Three phases, run by a group of NTG threads
+    // (t0 = index in the group) with a barrier between them; its LDS (patch, weights, partial sums) at `fbase`.
+    float fh_state = 0.f, fh_bias = 0.f;
+    // c0 / cn: the channels this thread group stages and multiplies (multiples of hid / 16)
+    // tfin: this thread's index among the 60 finishing threads (fh_finish), >= 60 for the others
+    auto fh_stage = [&](float* fbase, int t0, int NTG, int c0, int cn, int tfin, auto nb_c) {
+        constexpr int NB = decltype(nb_c)::value;  // patch loads of a thread in flight
+        const int hid = a.fh.hid;
+        float* patch = fbase;               // [hid][96]: 8 x 12 positions around the tile
+        float* fw = fbase + hid * 96;       // [hid][9]
+        const float* src = a.fh.x + b * a.fh.xbs;
+        // everything this phase reads from global memory is requested before anything is waited for: the weights (two per thread at
+        // most), the finishing threads' old coordinate and bias, then the patch
+        constexpr int NWL = 3;
+        float wreg[NWL];
+#pragma unroll
+        for (int k = 0; k < NWL; ++k) wreg[k] = a.fh.w[c0 * 9 + min(t0 + k * NTG, cn * 9 - 1)];
+        if (tfin < 60) {
+            fh_bias = a.fh.bias[0];
+            const int y = ty0 + tfin / 10 - 1, x = tx0 + tfin % 10 - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) fh_state = a.fh.coords_in[b * XP + pix_off(a.lay, y, x)];
+        }
+        const int total = 96 * (cn / 4);  // item = (position, 4 channels); clamped addresses, zero-filled by select
+        for (int e0 = t0; e0 < total; e0 += NB * NTG) {
+            float4 v[NB];
+            bool ok[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int e = min(e0 + j * NTG, total - 1);
+                const int pos = e % 96, q = c0 / 4 + e / 96;
+                const int gy = ty0 + pos / 12 - 2, gx = tx0 + pos % 12 - 2;
+                ok[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const long off = ok[j] ? pix_off(a.lay, gy, gx) : 0;
+                if (a.x_c4) v[j] = *reinterpret_cast<const float4*>(src + (long)q * 4 * XP + 4 * off);
+                else v[j] = make_float4(src[(long)(4 * q) * XP + off], src[(long)(4 * q + 1) * XP + off], src[(long)(4 * q + 2) * XP + off], src[(long)(4 * q + 3) * XP + off]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int e = e0 + j * NTG;
+                if (e < total) {
+                    float* pp = patch + (c0 + 4 * (e / 96)) * 96 + e % 96;
+                    pp[0] = ok[j] ? v[j].x : 0.f;
+                    pp[96] = ok[j] ? v[j].y : 0.f;
+                    pp[192] = ok[j] ? v[j].z : 0.f;
+                    pp[288] = ok[j] ? v[j].w : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWL; ++k)
+            if (t0 + k * NTG < cn * 9) fw[c0 * 9 + t0 + k * NTG] = wreg[k];
+        for (int e = t0 + NWL * NTG; e < cn * 9; e += NTG) fw[c0 * 9 + e] = a.fh.w[c0 * 9 + e];  // (thread groups smaller than cn * 9 / 3)
+    };
+    auto fh_partials = [&](float* fbase, int t0, int NTG, int c0, int cn) {
+        const int hid = a.fh.hid, cps = hid / 16, s0 = c0 / cps, ns = cn / cps;
+        const float* patch = fbase;
+        const float* fw = fbase + hid * 96;
+        float* part = fbase + hid * 105;    // [16][64] (60 used)
+        // (slice, patch position): flow_head2_kernel's partial sums; 4 tasks of a thread side by side (4 independent fmac chains)
+        for (int e0 = t0; e0 < ns * 60; e0 += 4 * NTG) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int po[4], sl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = min(e0 + k * NTG, ns * 60 - 1);
+                sl[k] = s0 + e / 60;
+                po[k] = (e % 60 / 10) * 12 + e % 60 % 10;
+            }
+            for (int cc = 0; cc < cps; ++cc) {
+                // a tap row of the 4 tasks at a time: its 24 LDS reads are issued together, then the 12 fmacs — behind the inline
+                // v_fmac_f32 of fmac_scalar the compiler waits for an operand where it is used, one LDS latency per fmac otherwise
+#pragma unroll
+                for (int tr = 0; tr < 3; ++tr) {
+                    float wv[4][3], xv[4][3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ci = sl[k] * cps + cc;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            wv[k][dx] = fw[ci * 9 + tr * 3 + dx];
+                            xv[k][dx] = patch[ci * 96 + po[k] + tr * 12 + dx];
+                        }
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) fmac_scalar(acc[k], wv[k][dx], xv[k][dx]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * NTG;
+                if (e < ns * 60) part[sl[k] * 64 + e % 60] = acc[k];
+            }
+        }
+    };
+    auto fh_finish = [&](float* fbase, int t0) {
+        if (t0 >= 60) return;
+        const float* part = fbase + a.fh.hid * 105;
+        const int pr = t0 / 10, pc = t0 % 10;
+        const int y = ty0 + pr - 1, x = tx0 + pc - 1;
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) sum += part[sl * 64 + t0];
+        sum += fh_bias;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const float cnew = fh_state + sum;
+        const float fl = a.fh.absolute ? cnew : cnew - (float)x;
+        fp[t0] = in ? fl : 0.f;
+        if (in && pr >= 1 && pr <= 4 && pc >= 1 && pc <= 8) {  // the tile's own pixels
+            const long pix = pix_off(a.lay, y, x);
+            a.fh.delta_out[b * XP + pix] = sum;
+            a.fh.coords_out[b * XP + pix] = cnew;
+            a.fh.flow_out[b * XP + pix] = fl;
+            a.fh.hx_flow[b * a.fh.hx_bs + pix * a.fh.hx_pm] = fl;
+        }
+    };
+    // the x tile's global loads of the split arithmetics are issued first: they are in flight while the folded flow head works
+    constexpr int NQ4 = (CIN / 4 * 32 + NT - 1) / NT;
+    float4 v4[SPLIT ? NQ4 : 1];
+    if constexpr (SPLIT) {  // (the flow-head waves, tid >= NT, load clamped addresses and never use them)
+        const float* src = a.x + b * a.xbs;
+#pragma unroll
+        for (int i = 0; i < NQ4; ++i) {
+            const int e = min(tid, NT - 1) + i * NT;
+            const int qd = e >> 5, px = e & 31;
+            const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
+            const bool ok = e < CIN / 4 * 32 && y < H && x < W;
+            if (a.x_c4) {
+                v4[i] = *reinterpret_cast<const float4*>(src + (ok ? (unsigned)(qd * 4 * (int)XP + 4 * (int)pix_off(a.lay, y, x)) : 0u));
+            } else {
+                const unsigned o = ok ? (unsigned)(qd * 4 * (int)XP + (int)pix_off(a.lay, y, x)) : 0u;
+                v4[i] = make_float4(src[o], src[ok ? o + (unsigned)XP : 0u], src[ok ? o + 2u * (unsigned)XP : 0u], src[ok ? o + 3u * (unsigned)XP : 0u]);
+            }
+        }
+    }
+    if constexpr (FHW > 0) {
+        // concurrent fold: EVERY thread helps staging the flow head's patch (3 more loads each, in flight with the x tile's; staged by the
+        // 4 flow-head waves alone the first barrier waited 4.8 us for their 12 loads per lane), then the flow-head waves go their own way:
+        // wave w multiplies slices 4w .. 4w + 3 beside the K loop; the 16 slice sums meet behind the K loop's barrier, the flow patch is
+        // there one barrier later.  Their four barriers are the GEMM path's.
+        float* fbase = lds + Cfg::LDS_FLOATS;
+        fh_stage(fbase, tid, NT + 64 * FHW, 0, a.fh.hid, tid >= NT ? tid - NT : 64, std::integral_constant<int, 3>{});
+        if (tid >= NT) {
+            const int fw_ = (tid - NT) >> 6, cn = a.fh.hid / FHW;
+            __syncthreads();  // (x tile and patch staged)
+            fh_partials(fbase, lane, 64, fw_ * cn, cn);
+            __syncthreads();  // (K loop done)
+            fh_finish(fbase, tid - NT);
+            __syncthreads();
+            __syncthreads();
+            return;
+        }
+    }
+    if constexpr (FHW == 0) {
+        if (a.fh.x) {  // serially, by everybody, in front of the x tile (whose LDS it borrows)
+            fh_stage(lds, tid, NT, 0, a.fh.hid, tid, std::integral_constant<int, 4>{});
+            __syncthreads();
+            fh_partials(lds, tid, NT, 0, a.fh.hid);
+            __syncthreads();
+            fh_finish(lds, tid);
+            __syncthreads();  // patch / weights / partial sums are dead: the x tile may overwrite them
+        }
+    }
     // ---- stage the x tile (all CIN channels) and the flow patch
     {
         const float* src = a.x + b * a.xbs;
         if constexpr (SPLIT) {
-            // item = (pixel, 4 consecutive channels): one 16-B load (c4) or four 4-B loads, split into NS x 4 16-bit pieces = NS 8-B stores
+            // item = (pixel, 4 consecutive channels): one 16-B load (c4) or four 4-B loads (issued above, in front of the folded flow head),
+            // split into NS x 4 16-bit pieces = NS 8-B stores
             unsigned char* xsb = reinterpret_cast<unsigned char*>(lds);
-            constexpr int NQ4 = (CIN / 4 * 32 + NT - 1) / NT;
-            float4 v4[NQ4];
-#pragma unroll
-            for (int i = 0; i < NQ4; ++i) {
-                const int e = tid + i * NT;
-                const int qd = e >> 5, px = e & 31;
-                const int y = ty0 + (px >> 3), x = tx0 + (px & 7);
-                const bool ok = e < CIN / 4 * 32 && y < H && x < W;
-                if (a.x_c4) {
-                    v4[i] = *reinterpret_cast<const float4*>(src + (ok ? (unsigned)(qd * 4 * (int)XP + 4 * (int)pix_off(a.lay, y, x)) : 0u));
-                } else {
-                    const unsigned o = ok ? (unsigned)(qd * 4 * (int)XP + (int)pix_off(a.lay, y, x)) : 0u;
-                    v4[i] = make_float4(src[o], src[ok ? o + (unsigned)XP : 0u], src[ok ? o + 2u * (unsigned)XP : 0u], src[ok ? o + 3u * (unsigned)XP : 0u]);
-                }
-            }
 #pragma unroll
             for (int i = 0; i < NQ4; ++i) {
                 const int e = tid + i * NT;
@@ -173,7 +333,7 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
             if (e < CIN * 32) xs[e] = ok ? v[i] : 0.f;
         }
         }
-        if (tid < 60 * a.fc) {
+        if (!a.fh.x && tid < 60 * a.fc) {
             const int f = tid / 60, pos = tid % 60;
             const int pr = pos / 10, pc = pos % 10;
             const int y = ty0 + pr - 1, x = tx0 + pc - 1;
@@ -336,19 +496,31 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT)) mask_upsample_kern
     NND_MSTAMP(4);
 }
 
-template <int RATE, int CIN, int NS = 0>
-static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
+constexpr int MU_FHW = 4;  // flow-head waves of the concurrent fold (fp16x2: 105 VGPRs, 16 waves per CU fit)
+template <int RATE, int CIN, int NS, int FHW>
+static int launch_mu_fhw(MaskUpArgs a, int B, hipStream_t stream) {
     using Cfg = MaskUpCfg<RATE, CIN>;
-    auto kern = mask_upsample_kernel<RATE, CIN, NS>;
-    const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
+    auto kern = mask_upsample_kernel<RATE, CIN, NS, FHW>;
+    a.lds_floats = Cfg::LDS_FLOATS;
+    const int fh_floats = a.fh.x ? a.fh.hid * (96 + 9) + 16 * 64 : 0;  // the folded flow head's patch, weights, partial sums
+    if (FHW > 0) a.lds_floats = Cfg::LDS_FLOATS + fh_floats + 128;      // behind the GEMM's LDS
+    else if (a.fh.x) a.lds_floats = std::max(a.lds_floats, fh_floats + 128);  // borrowed from the x tile
+    const size_t lds = a.lds_floats * sizeof(float);
     if (lds > 64 * 1024) {
         static std::atomic<unsigned> raised{0};
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(kern), raised)) return rc;
     }
-    dim3 grid(a.tiles_x * cdiv(a.H, 4), 1, B), block(Cfg::NT);
+    dim3 grid(a.tiles_x * cdiv(a.H, 4), 1, B), block(Cfg::NT + 64 * FHW);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
     NND_LAUNCH_CHECK();
     return NND_OK;
+}
+template <int RATE, int CIN, int NS = 0>
+static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
+    if constexpr (NS == 2) {  // NND_MU_SERIAL_FOLD (diagnostic): the fold by all threads in front of the x tile, as for the other arithmetics
+        if (a.fh.x && !switches().mu_serial_fold) return launch_mu_fhw<RATE, CIN, NS, MU_FHW>(a, B, stream);
+    }
+    return launch_mu_fhw<RATE, CIN, NS, 0>(a, B, stream);
 }
 
 bool mask_upsample_supported(int rate, int cin, int flow_channels) {
@@ -356,7 +528,8 @@ bool mask_upsample_supported(int rate, int cin, int flow_channels) {
 }
 
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
-                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels, bool x_c4) {
+                         int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels, bool x_c4,
+                         const MaskUpFlowHead* fh) {
     NND_REQUIRE(L.KH == 1 && L.KW == 1 && L.CI_T == (L.arith ? 16 : 128) && L.Cout == 9 * rate * rate && (L.arith == 0 || L.arith == 3 || L.arith == 2),
                 "mask_upsample: layer shape / packing");
     NND_REQUIRE(mask_upsample_supported(rate, L.Cin, flow_channels), "mask_upsample: rate %d / Cin %d / %d flow channels not built",
@@ -366,6 +539,14 @@ int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, 
     a.H = H; a.W = W; a.tiles_x = cdiv(W, 8); a.fc = flow_channels;
     a.lay = make_lay(H, W, tiled);
     a.x_c4 = (tiled && x_c4) ? 1 : 0;
+    a.lds_floats = 0;
+    a.fh = MaskUpFlowHead{};
+    if (fh && fh->x) {
+        NND_REQUIRE(flow_channels == 1 && fh->hid % 16 == 0 && fh->w && fh->bias && fh->coords_in && fh->coords_out && fh->flow_out &&
+                        fh->delta_out && fh->hx_flow && fh->coords_in != fh->coords_out,
+                    "mask_upsample: folded flow head needs one flow channel, hid %% 16 == 0 and distinct old / new state buffers");
+        a.fh = *fh;
+    }
     if (L.arith == 3) {  // split-bf16 arithmetic: weights in pack_conv_split's order
         if (rate == 8 && L.Cin == 256) return launch_mu<8, 256, 3>(a, B, stream);
         if (rate == 8 && L.Cin == 128) return launch_mu<8, 128, 3>(a, B, stream);

@@ -854,6 +854,11 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool no_fuse_up = switches().no_fused_upsample;  // the parity tests toggle these (nnd_reload_switches)
     const bool no_fuse_lk = switches().no_fused_lookup;
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
+    // flow_head.conv2 folded into the fused mask / upsample launch: 1-channel flow (not CREStereo); NND_NO_FOLDED_FLOW_HEAD: two launches.
+    // The second (coordinate, flow) buffer pair lives in the mask buffer, which the fused upsample never writes.
+    const bool fold_fh = fused_up && !cre && fc == 1 && hid % 16 == 0 && !switches().no_folded_flow_head;
+    float* coords_alt = w.mask;
+    float* flow_alt = w.mask + ((int64_t)B * n + 63) / 64 * 64;
     const bool fused_lk = !cre && !no_fuse_lk && flat_groups == 0;  // (the group-RAFT lookup gathers other pixels' rows: stand-alone kernel)
     const bool merged_fbl = fused_lk && !igev && !switches().no_merged_fb_lookup && !switches().no_fused_flow_branch &&
                             flow_branch_supported(p.L[C_F2], fc) && flow_branch_lookup_supported(p.L[C_F2].arith);
@@ -903,8 +908,23 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
             NND_TRY(loop_conv(C_Q2X));
         }
         NND_TRY(loop_conv(C_FHM));  // flow_head.conv1 and mask.0 in one launch
-        NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
         float* up_it = up_out + (int64_t)it * up_iter_stride;
+        if (fold_fh) {
+            // flow_head.conv2 + the recurrence update inside the mask / upsample launch (mask_upsample.hip: MaskUpFlowHead): it reads
+            // the old coordinate and writes the new state into the other buffer pair (a workgroup's halo belongs to its neighbours)
+            MaskUpFlowHead fh;
+            fh.x = w.fm; fh.xbs = (int64_t)3 * hid * n; fh.hid = hid;
+            fh.w = packed + p.fc2_w; fh.bias = packed + p.fc2_b;
+            fh.coords_in = w.coords; fh.coords_out = coords_alt; fh.flow_out = flow_alt; fh.delta_out = w.delta;
+            fh.hx_flow = hx_flow; fh.hx_bs = (long)(hxC * n); fh.hx_pm = ws_pm(); fh.absolute = igev ? 1 : 0;
+            NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow, up_it, B, H, W, rate, s,
+                                         true, fc, ws_c4(), &fh));
+            NND_TRY(debug_sync("flow_head.conv2 + mask.2 + upsample", s));
+            std::swap(w.coords, coords_alt);
+            std::swap(w.flow, flow_alt);
+            continue;
+        }
+        NND_TRY(run_fc2(p, packed, w, w.delta, cre ? 2 : 1, igev, B, H, W, s));
         if (fused_up) {  // mask.2 + softmax + upsample in one kernel: the 9*r*r-channel mask never reaches HBM
             NND_TRY(mask_upsample_launch(p.L[C_M2], packed, w.fm + hid * n, (int64_t)3 * hid * n, w.flow, up_it, B, H, W, rate, s,
                                          true, fc, ws_c4()));

@@ -498,6 +498,57 @@ def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monke
         assert torch.equal(x, y), (i, float((x - y).abs().max()))
 
 
+@pytest.mark.parametrize("arithmetic", ["fp16x2", "fp32"])
+def test_folded_flow_head_is_bit_identical_to_its_own_launch(monkeypatch, arithmetic):
+    """Round 4: flow_head.conv2 and the recurrence update run inside the fused mask / upsample launch (mask_upsample.hip: MaskUpFlowHead;
+    old and new state in two buffer pairs).  flow_head2_kernel's arithmetic: against the separate launch (NND_NO_FOLDED_FLOW_HEAD) every
+    output of the loops — upsampled maps of all iterations, final low-resolution state, hidden state — must match bit for bit:
+    RAFT-Stereo (ragged 13x22 map, batch 2; disparity given), IGEV (absolute coordinates, rate 4, hidden 64), the Coarse2Fine stage
+    (conv_gru, rate 4, group lookup)."""
+    from nndepth_amd import ops, weightgen
+    from nndepth_amd.blocks import BasicUpdateBlock
+    from nndepth_amd.cost_volume import CorrBlock1D
+
+    def run():
+        torch.manual_seed(52)
+        outs = []
+        B, H, W = 2, 13, 22
+        ub = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=64, flow_channel=1, spatial_scale=8, arithmetic=arithmetic)
+        weightgen.fill_module_(ub, "update_block.")
+        eng = ub.to(DEV).eval().sync_engine(DEV)
+        net, inp = torch.tanh(torch.randn(B, 128, H, W)).to(DEV), torch.relu(torch.randn(B, 64, H, W)).to(DEV)
+        f1, f2 = torch.randn(B, 256, H, W, device=DEV), torch.randn(B, 256, H, W, device=DEV)
+        init = (torch.rand(B, 1, H, W, device=DEV) - 0.5) * 6
+        outs += [o.clone() for o in eng.refine(CorrBlock1D(f1, f2, 4, 4)._pyr, 4, 4, net, inp, 8, 5, disp_init=init)]
+        # IGEV: hidden 64, 576 lookup channels, absolute coordinates
+        B, H, W, G = 1, 12, 24, 8
+        ub2 = BasicUpdateBlock(hidden_dim=64, cor_planes=576, context_dim=64, flow_channel=1, spatial_scale=4, arithmetic=arithmetic)
+        weightgen.fill_module_(ub2, "igev.update_block.")
+        eng2 = ub2.to(DEV).eval().sync_engine(DEV)
+        net, inp = torch.tanh(torch.randn(B, 64, H, W)).to(DEV), torch.relu(torch.randn(B, 64, H, W)).to(DEV)
+        fp_ = ops.group_corr_build(torch.randn(B, 64, H, W, device=DEV), torch.randn(B, 64, H, W, device=DEV), G, 8, 4)
+        gp_ = ops.group_corr_build(torch.randn(B, 64, H, W, device=DEV), torch.randn(B, 64, H, W, device=DEV), G, 8, 4)
+        outs += [o.clone() for o in eng2.refine_igev(fp_, gp_, G, 4, 4, net, inp, 4, 4, disp_init=torch.rand(B, 1, H, W, device=DEV) * 3)]
+        # Coarse2Fine stage: conv_gru, group lookup, rate 4
+        B, H, W = 1, 9, 20
+        ub3 = BasicUpdateBlock(hidden_dim=128, cor_planes=36, context_dim=128, flow_channel=1, spatial_scale=(4, 4), gru="conv_gru",
+                               arithmetic=arithmetic)
+        weightgen.fill_module_(ub3, "c2f.update_block.")
+        eng3 = ub3.to(DEV).eval().sync_engine(DEV)
+        net, inp = torch.tanh(torch.randn(B, 128, H, W)).to(DEV), torch.relu(torch.randn(B, 128, H, W)).to(DEV)
+        gpyr = ops.raft_group_corr_build(torch.randn(B, 64, H, W, device=DEV), torch.randn(B, 64, H, W, device=DEV), 4, 1)
+        outs += [o.clone() for o in eng3.refine_group(gpyr, 4, 1, 4, net, inp, 4, 3)]
+        return outs
+
+    a = run()
+    monkeypatch.setenv("NND_NO_FOLDED_FLOW_HEAD", "1")
+    b = run()
+    assert len(a) == len(b) == 9
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.isfinite(x).all() and x.abs().max() > 0
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
 def test_loop_conv_probe_and_its_event_pair_calibration():
     """bench.py's live measurement of a conv inside the fused loop (nnd_profile_loop_conv: events around the launch in every
     iteration) and its calibration (nnd_profile_loop_event_pair: both events in front of the conv): both run the loop, the empty
