@@ -240,16 +240,90 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT + 64 * FHW)) mask_up
         }
     }
     if constexpr (FHW > 0) {
-        // concurrent fold: EVERY thread helps staging the flow head's patch (3 more loads each, in flight with the x tile's; staged by the
-        // 4 flow-head waves alone the first barrier waited 4.8 us for their 12 loads per lane), then the flow-head waves go their own way:
-        // wave w multiplies slices 4w .. 4w + 3 beside the K loop; the 16 slice sums meet behind the K loop's barrier, the flow patch is
-        // there one barrier later.  Their four barriers are the GEMM path's.
-        float* fbase = lds + Cfg::LDS_FLOATS;
-        fh_stage(fbase, tid, NT + 64 * FHW, 0, a.fh.hid, tid >= NT ? tid - NT : 64, std::integral_constant<int, 3>{});
         if (tid >= NT) {
-            const int fw_ = (tid - NT) >> 6, cn = a.fh.hid / FHW;
-            __syncthreads();  // (x tile and patch staged)
-            fh_partials(fbase, lane, 64, fw_ * cn, cn);
+            // concurrent fold: flow-head wave w stages and multiplies its own hid / FHW channels (slices 4w .. 4w + 3).  Its 12 patch loads
+            // per lane are ISSUED here, in front of the first barrier — beside the x tile's, before the GEMM's weight stream takes the
+            // vector-memory pipe — but that barrier is a bare s_barrier for these waves (they publish nothing there; __syncthreads would
+            // wait for the loads and with it hold the GEMM back: staging phase 2.8 -> 6.6 us).  The data is waited for behind it, goes to
+            // LDS, is multiplied (wave-local: no workgroup barrier in between) while the GEMM runs its K loop; the 16 slice sums meet
+            // behind the K loop's barrier, the flow patch is there one barrier later.
+            float* fbase = lds + Cfg::LDS_FLOATS;
+            const int hid = a.fh.hid, fw_ = __builtin_amdgcn_readfirstlane((tid - NT) >> 6), cn = hid / FHW, c0 = fw_ * cn;
+            float* patch = fbase;
+            float* fw = fbase + hid * 96;
+            const float* src = a.fh.x + b * a.fh.xbs;
+            constexpr int NPL = 12, NWL = 5;  // per lane: patch items (hid <= 128: 96 * (hid / 16) / 64) and weights (hid / 4 * 9 / 64)
+            const int total = 96 * (cn / 4), nwt = cn * 9;
+            float4 pv[NPL];
+            bool pok[NPL];
+            float wreg[NWL];
+#pragma unroll
+            for (int k = 0; k < NWL; ++k) wreg[k] = a.fh.w[c0 * 9 + min(lane + 64 * k, nwt - 1)];
+            if (tid - NT < 60) {
+                fh_bias = a.fh.bias[0];
+                const int y = ty0 + (tid - NT) / 10 - 1, x = tx0 + (tid - NT) % 10 - 1;
+                if (y >= 0 && y < H && x >= 0 && x < W) fh_state = a.fh.coords_in[b * XP + pix_off(a.lay, y, x)];
+            }
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int e = min(lane + 64 * j, total - 1);
+                const int pos = e % 96, q = c0 / 4 + e / 96;
+                const int gy = ty0 + pos / 12 - 2, gx = tx0 + pos % 12 - 2;
+                pok[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const long off = pok[j] ? pix_off(a.lay, gy, gx) : 0;
+                if (a.x_c4) pv[j] = *reinterpret_cast<const float4*>(src + (long)q * 4 * XP + 4 * off);
+                else pv[j] = make_float4(src[(long)(4 * q) * XP + off], src[(long)(4 * q + 1) * XP + off], src[(long)(4 * q + 2) * XP + off], src[(long)(4 * q + 3) * XP + off]);
+            }
+            __builtin_amdgcn_s_barrier();  // (x tile staged) — bare: the loads above stay in flight
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int e = lane + 64 * j;
+                if (e < total) {
+                    float* pp = patch + (c0 + 4 * (e / 96)) * 96 + e % 96;
+                    pp[0] = pok[j] ? pv[j].x : 0.f;
+                    pp[96] = pok[j] ? pv[j].y : 0.f;
+                    pp[192] = pok[j] ? pv[j].z : 0.f;
+                    pp[288] = pok[j] ? pv[j].w : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NWL; ++k)
+                if (lane + 64 * k < nwt) fw[c0 * 9 + lane + 64 * k] = wreg[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the wave's own LDS writes before its own reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            {   // the wave's 4 slices x 60 positions: lane = position, the 4 slices side by side; the 36 values and 36 (wave-uniform:
+                // broadcast) weights of a channel step are read from LDS together: 8 LDS round trips per lane — under the K loop's
+                // ds_read_b128 stream a round trip is long, and 24 of them (a tap row at a time) kept the K loop's barrier waiting for
+                // these waves.  (Weights straight from global memory became vector loads queued behind the GEMM's weight stream.)
+                const int cps = hid / 16, s0 = c0 / cps;
+                const int pos = min(lane, 59), po = (pos / 10) * 12 + pos % 10;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int cc = 0; cc < cps; ++cc) {
+                    float xv[4][9];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float* pp = patch + ((s0 + k) * cps + cc) * 96 + po;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) xv[k][t] = pp[(t / 3) * 12 + t % 3];
+                    }
+                    float wv[4][9];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float* wk = fw + ((s0 + k) * cps + cc) * 9;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) wv[k][t] = wk[t];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) fmac_scalar(acc[k], wv[k][t], xv[k][t]);
+                }
+                float* part = fbase + hid * 105;
+                if (lane < 60)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) part[(s0 + k) * 64 + pos] = acc[k];
+            }
             __syncthreads();  // (K loop done)
             fh_finish(fbase, tid - NT);
             __syncthreads();
@@ -518,7 +592,7 @@ static int launch_mu_fhw(MaskUpArgs a, int B, hipStream_t stream) {
 template <int RATE, int CIN, int NS = 0>
 static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
     if constexpr (NS == 2) {  // NND_MU_SERIAL_FOLD (diagnostic): the fold by all threads in front of the x tile, as for the other arithmetics
-        if (a.fh.x && !switches().mu_serial_fold) return launch_mu_fhw<RATE, CIN, NS, MU_FHW>(a, B, stream);
+        if (a.fh.x && a.fh.hid <= 128 && !switches().mu_serial_fold) return launch_mu_fhw<RATE, CIN, NS, MU_FHW>(a, B, stream);
     }
     return launch_mu_fhw<RATE, CIN, NS, 0>(a, B, stream);
 }
