@@ -21,7 +21,7 @@
  *   - diagnostic environment switches (read ONCE when the library is loaded and again only by nnd_reload_switches(), never
  *     on the hot path; they select between kernels that the parity tests prove equivalent, never a non-HIP path; none of them
  *     changes the layout of a packed blob — which convolutions of the update block take a split arithmetic is part of the
- *     descriptor, nnd_update_block_desc.split_layers): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches), NND_NO_FOLDED_FLOW_HEAD (flow_head.conv2 + the recurrence update as their own launch in front of the fused mask / upsample launch instead of inside it), NND_MU_SERIAL_FOLD (that fold by all threads in front of the mask GEMM instead of by four extra waves beside it),
+ *     descriptor, nnd_update_block_desc.split_layers): NND_NO_FUSED_UPSAMPLE (mask.2 and convex upsample as two launches), NND_NO_FOLDED_FLOW_HEAD (flow_head.conv2 + the recurrence update as their own launch in front of the fused mask / upsample launch instead of inside it),
  *     NND_NO_FUSED_LOOKUP (lookup and convc1 as two launches), NND_NO_MERGED_FB_LOOKUP (flow branch and lookup + convc1 as two launches instead of one launch of two kinds of workgroups), NND_DEBUG_LDS_POISON / NND_DEBUG_LDS_SLACK (diagnostics of the round-3 reproducibility study: pattern-fill every CU's LDS between the loop's launches / ask for more dynamic LDS), NND_SPLIT_NO_FAST (the generic conv_split kernel wherever one exists: every stride-1 shape; the stride-2 kernels are FAST-only and keep running), NND_NO_FUSED_FLOW_BRANCH (convf1 and convf2 as two launches when
  *     arithmetic = 3), NND_SPLIT_CFG (force the workgroup shape of the split kernel), NND_NO_CONV1X1_STREAM (1x1 shortcuts through the
  *     staged conv kernel), NND_CORR_BUILD_V1 (register-operand correlation build), NND_CORR_BUILD_NO_KSPLIT (small grids through the LDS-staged build instead of the k-split one), NND_IGEV_SQUEEZE_V1 / NND_IGEV_SQUEEZE_WALK (cv_squeezer + soft-argmin: the one-row kernel always / the row-walking kernel whenever it can run), NND_AGCL_V1 (one-pixel-per-lane AGCL kernels), NND_AGCL_PB (pixels per workgroup of the channels-last offset kernel), NND_CONV_CFG / NND_CONV_P

@@ -40,7 +40,7 @@ void set_error(const char* fmt, ...);
 // loaded and again only by nnd_reload_switches(); the hot path never calls getenv.  They select between kernels that the parity
 // tests prove equivalent, never a non-HIP path.
 struct Switches {
-    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, corr_build_no_ksplit, igev_squeeze_v1, igev_squeeze_walk, no_folded_flow_head, mu_serial_fold, no_conv1x1_stream,
+    bool no_fused_upsample, no_fused_lookup, no_fused_flow_branch, no_c4, agcl_v1, no_thin3d, corr_build_v1, corr_build_no_ksplit, igev_squeeze_v1, igev_squeeze_walk, no_folded_flow_head, no_conv1x1_stream,
         conv_verbose, debug_sync;
     int split_ny, split_ks, split_p;  // NND_SPLIT_CFG=ny,ks[,P] (<= 0: the picker decides)
     bool split_no_fast;               // NND_SPLIT_NO_FAST: the generic conv_split kernel also where the FAST regime applies
@@ -240,7 +240,8 @@ int igev_lookup_convc1_il_launch(const float* il, int G, const float* coords, co
 // channels x 9 taps with v_fmac_f32 each, summed in slice order, + bias: the same bits) — and adds it to the OLD coordinate.  Old
 // and new state live in two buffer pairs that the caller swaps every iteration (a neighbour workgroup may already have advanced
 // the pixels of this one's halo); the 32 pixels of the tile itself are written: new coordinate, new flow (also into the GRU's
-// input tensor) and delta.  Saves the flow_head2 launch (6.9 us + the gap behind it) for ~2 us in here.
+// input tensor) and delta.  Four extra waves do it beside the mask GEMM (fp16x2 kernels): the launch it saves is 8.7 us, 2-3 us of them
+// are gained — on grids of at most two workgroups per CU; on larger ones the separate launch is as fast or faster and is kept.
 struct MaskUpFlowHead {
     const float* x;       // flow head's hidden map relu(flow_head.conv1(h)): hid channels, layout `lay` / x_c4 of the mask input
     long xbs;
@@ -256,6 +257,7 @@ struct MaskUpFlowHead {
 };
 
 bool mask_upsample_supported(int rate, int cin, int flow_channels);
+bool mask_upsample_fold_supported(const ConvLayer& L, int hid);
 int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, int64_t xbs, const float* flow, float* out,
                          int B, int H, int W, int rate, hipStream_t stream, bool tiled, int flow_channels = 1, bool x_c4 = false,
                          const MaskUpFlowHead* fh = nullptr);

@@ -27,7 +27,6 @@ static void load_switches() {
     s.igev_squeeze_v1 = on("NND_IGEV_SQUEEZE_V1");
     s.igev_squeeze_walk = on("NND_IGEV_SQUEEZE_WALK");
     s.no_folded_flow_head = on("NND_NO_FOLDED_FLOW_HEAD");
-    s.mu_serial_fold = on("NND_MU_SERIAL_FOLD");
     s.no_conv1x1_stream = on("NND_NO_CONV1X1_STREAM");
     s.conv_verbose = on("NND_CONV_VERBOSE");
     s.debug_sync = on("NND_DEBUG_SYNC");

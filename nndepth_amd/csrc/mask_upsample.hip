@@ -71,8 +71,8 @@ struct MaskUpCfg {
 // mask GEMM — the flow head is a latency chain (hidden map from HBM -> 60 dot products -> new state) that nothing in the GEMM waits
 // for until the upsample reads the flow patch; its LDS lies behind the GEMM's.  The four barriers of the GEMM path (x tile staged |
 // K loop done | first K half in the mask tile | second) are the flow head's: patch staged | partial sums | new flow patch written |
-// (nothing).  FHW = 0 with fh.x set: the same work by all threads, serially in front of the x tile (the arithmetics whose GEMM waves
-// need more than 128 VGPRs, which 16 waves per CU do not leave).
+// (nothing).  Instantiated for fp16x2 (105 VGPRs: 16 waves per CU fit; the other arithmetics' GEMM waves need more than 128).  The
+// same work by all threads in front of the x tile was measured too: never faster than the separate launch, 5 % slower at batch 8.
 template <int RATE, int CIN, int NS = 0, int FHW = 0>
 __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT + 64 * FHW)) mask_upsample_kernel(MaskUpArgs a) {
     constexpr bool SPLIT = NS != 0;
@@ -103,102 +103,9 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT + 64 * FHW)) mask_up
         xscale = a.bias[Cfg::NCB * 32 + SPLIT_TAIL_XSCALE];
     }
 
-    // ---- folded flow_head.conv2 + recurrence update (MaskUpFlowHead): the new flow patch.  Three phases, run by a group of NTG threads
-    // (t0 = index in the group) with a barrier between them; its LDS (patch, weights, partial sums) at `fbase`.
+    // ---- folded flow_head.conv2 + recurrence update (MaskUpFlowHead): run by FHW extra waves (below); their LDS (patch, weights,
+    // partial sums) at `fbase`, behind the GEMM's.  Last step: the 16 slice sums + bias, the new state, the flow patch.
     float fh_state = 0.f, fh_bias = 0.f;
-    // c0 / cn: the channels this thread group stages and multiplies (multiples of hid / 16)
-    // tfin: this thread's index among the 60 finishing threads (fh_finish), >= 60 for the others
-    auto fh_stage = [&](float* fbase, int t0, int NTG, int c0, int cn, int tfin, auto nb_c) {
-        constexpr int NB = decltype(nb_c)::value;  // patch loads of a thread in flight
-        const int hid = a.fh.hid;
-        float* patch = fbase;               // [hid][96]: 8 x 12 positions around the tile
-        float* fw = fbase + hid * 96;       // [hid][9]
-        const float* src = a.fh.x + b * a.fh.xbs;
-        // everything this phase reads from global memory is requested before anything is waited for: the weights (two per thread at
-        // most), the finishing threads' old coordinate and bias, then the patch
-        constexpr int NWL = 3;
-        float wreg[NWL];
-#pragma unroll
-        for (int k = 0; k < NWL; ++k) wreg[k] = a.fh.w[c0 * 9 + min(t0 + k * NTG, cn * 9 - 1)];
-        if (tfin < 60) {
-            fh_bias = a.fh.bias[0];
-            const int y = ty0 + tfin / 10 - 1, x = tx0 + tfin % 10 - 1;
-            if (y >= 0 && y < H && x >= 0 && x < W) fh_state = a.fh.coords_in[b * XP + pix_off(a.lay, y, x)];
-        }
-        const int total = 96 * (cn / 4);  // item = (position, 4 channels); clamped addresses, zero-filled by select
-        for (int e0 = t0; e0 < total; e0 += NB * NTG) {
-            float4 v[NB];
-            bool ok[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int e = min(e0 + j * NTG, total - 1);
-                const int pos = e % 96, q = c0 / 4 + e / 96;
-                const int gy = ty0 + pos / 12 - 2, gx = tx0 + pos % 12 - 2;
-                ok[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const long off = ok[j] ? pix_off(a.lay, gy, gx) : 0;
-                if (a.x_c4) v[j] = *reinterpret_cast<const float4*>(src + (long)q * 4 * XP + 4 * off);
-                else v[j] = make_float4(src[(long)(4 * q) * XP + off], src[(long)(4 * q + 1) * XP + off], src[(long)(4 * q + 2) * XP + off], src[(long)(4 * q + 3) * XP + off]);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int e = e0 + j * NTG;
-                if (e < total) {
-                    float* pp = patch + (c0 + 4 * (e / 96)) * 96 + e % 96;
-                    pp[0] = ok[j] ? v[j].x : 0.f;
-                    pp[96] = ok[j] ? v[j].y : 0.f;
-                    pp[192] = ok[j] ? v[j].z : 0.f;
-                    pp[288] = ok[j] ? v[j].w : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NWL; ++k)
-            if (t0 + k * NTG < cn * 9) fw[c0 * 9 + t0 + k * NTG] = wreg[k];
-        for (int e = t0 + NWL * NTG; e < cn * 9; e += NTG) fw[c0 * 9 + e] = a.fh.w[c0 * 9 + e];  // (thread groups smaller than cn * 9 / 3)
-    };
-    auto fh_partials = [&](float* fbase, int t0, int NTG, int c0, int cn) {
-        const int hid = a.fh.hid, cps = hid / 16, s0 = c0 / cps, ns = cn / cps;
-        const float* patch = fbase;
-        const float* fw = fbase + hid * 96;
-        float* part = fbase + hid * 105;    // [16][64] (60 used)
-        // (slice, patch position): flow_head2_kernel's partial sums; 4 tasks of a thread side by side (4 independent fmac chains)
-        for (int e0 = t0; e0 < ns * 60; e0 += 4 * NTG) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            int po[4], sl[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = min(e0 + k * NTG, ns * 60 - 1);
-                sl[k] = s0 + e / 60;
-                po[k] = (e % 60 / 10) * 12 + e % 60 % 10;
-            }
-            for (int cc = 0; cc < cps; ++cc) {
-                // a tap row of the 4 tasks at a time: its 24 LDS reads are issued together, then the 12 fmacs — behind the inline
-                // v_fmac_f32 of fmac_scalar the compiler waits for an operand where it is used, one LDS latency per fmac otherwise
-#pragma unroll
-                for (int tr = 0; tr < 3; ++tr) {
-                    float wv[4][3], xv[4][3];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int ci = sl[k] * cps + cc;
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            wv[k][dx] = fw[ci * 9 + tr * 3 + dx];
-                            xv[k][dx] = patch[ci * 96 + po[k] + tr * 12 + dx];
-                        }
-                    }
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) fmac_scalar(acc[k], wv[k][dx], xv[k][dx]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + k * NTG;
-                if (e < ns * 60) part[sl[k] * 64 + e % 60] = acc[k];
-            }
-        }
-    };
     auto fh_finish = [&](float* fbase, int t0) {
         if (t0 >= 60) return;
         const float* part = fbase + a.fh.hid * 105;
@@ -329,16 +236,6 @@ __global__ void __launch_bounds__((MaskUpCfg<RATE, CIN>::NT + 64 * FHW)) mask_up
             __syncthreads();
             __syncthreads();
             return;
-        }
-    }
-    if constexpr (FHW == 0) {
-        if (a.fh.x) {  // serially, by everybody, in front of the x tile (whose LDS it borrows)
-            fh_stage(lds, tid, NT, 0, a.fh.hid, tid, std::integral_constant<int, 4>{});
-            __syncthreads();
-            fh_partials(lds, tid, NT, 0, a.fh.hid);
-            __syncthreads();
-            fh_finish(lds, tid);
-            __syncthreads();  // patch / weights / partial sums are dead: the x tile may overwrite them
         }
     }
     // ---- stage the x tile (all CIN channels) and the flow patch
@@ -578,7 +475,6 @@ static int launch_mu_fhw(MaskUpArgs a, int B, hipStream_t stream) {
     a.lds_floats = Cfg::LDS_FLOATS;
     const int fh_floats = a.fh.x ? a.fh.hid * (96 + 9) + 16 * 64 : 0;  // the folded flow head's patch, weights, partial sums
     if (FHW > 0) a.lds_floats = Cfg::LDS_FLOATS + fh_floats + 128;      // behind the GEMM's LDS
-    else if (a.fh.x) a.lds_floats = std::max(a.lds_floats, fh_floats + 128);  // borrowed from the x tile
     const size_t lds = a.lds_floats * sizeof(float);
     if (lds > 64 * 1024) {
         static std::atomic<unsigned> raised{0};
@@ -591,11 +487,15 @@ static int launch_mu_fhw(MaskUpArgs a, int B, hipStream_t stream) {
 }
 template <int RATE, int CIN, int NS = 0>
 static int launch_mu(const MaskUpArgs& a, int B, hipStream_t stream) {
-    if constexpr (NS == 2) {  // NND_MU_SERIAL_FOLD (diagnostic): the fold by all threads in front of the x tile, as for the other arithmetics
-        if (a.fh.x && a.fh.hid <= 128 && !switches().mu_serial_fold) return launch_mu_fhw<RATE, CIN, NS, MU_FHW>(a, B, stream);
+    if (a.fh.x) {
+        if constexpr (NS == 2) return launch_mu_fhw<RATE, CIN, NS, MU_FHW>(a, B, stream);
+        else NND_REQUIRE(false, "mask_upsample: the folded flow head is built for the fp16x2 arithmetic");
     }
     return launch_mu_fhw<RATE, CIN, NS, 0>(a, B, stream);
 }
+
+// the folded flow head exists for this mask layer / hidden size (the caller decides whether it pays: small grids)
+bool mask_upsample_fold_supported(const ConvLayer& L, int hid) { return L.arith == 2 && hid % 16 == 0 && hid <= 128; }
 
 bool mask_upsample_supported(int rate, int cin, int flow_channels) {
     return (flow_channels == 1 || flow_channels == 2) && ((rate == 8 && (cin == 256 || cin == 128)) || (rate == 4 && (cin == 256 || cin == 128)));
@@ -616,7 +516,7 @@ int mask_upsample_launch(const ConvLayer& L, const float* blob, const float* x, 
     a.lds_floats = 0;
     a.fh = MaskUpFlowHead{};
     if (fh && fh->x) {
-        NND_REQUIRE(flow_channels == 1 && fh->hid % 16 == 0 && fh->w && fh->bias && fh->coords_in && fh->coords_out && fh->flow_out &&
+        NND_REQUIRE(flow_channels == 1 && mask_upsample_fold_supported(L, fh->hid) && fh->w && fh->bias && fh->coords_in && fh->coords_out && fh->flow_out &&
                         fh->delta_out && fh->hx_flow && fh->coords_in != fh->coords_out,
                     "mask_upsample: folded flow head needs one flow channel, hid %% 16 == 0 and distinct old / new state buffers");
         a.fh = *fh;
