@@ -2,6 +2,7 @@
     config 3  IGEV hot path at 544x960 (136x240 at 1/4): volume, regulariser, init, 32-iteration loop, batch 1 and 8
     config 4  RAFT-Stereo, 8 x 384x1248 (KITTI padded), 32 iterations
     config 5  CREStereo 1080x1920, 20 iterations: single cascade and the 2-stage harness
+    widening  Coarse2Fine RAFT-Stereo 512x960, 3 stages x 12 iterations (the class defaults), test double's encoder side
     python scripts/bench_configs.py [fp32,bf16x3,fp16x2]           (on the GPU box)"""
 import os
 import sys
@@ -53,6 +54,15 @@ def main():
         best = timeit.best
         ms2 = timeit(lambda: two_stage_forward(m, f1, f2), 9)
         print(f"config 5 per-GPU work [{ar}]: CREStereo 1080x1920, 20 iters: cascade {ms:.1f} ms / pair (median of 9; best {best:.1f}), 2-stage harness {ms2:.1f} ms / pair", flush=True)
+    elif which == "c2f":
+        from c2f_double import make_c2f
+        from nndepth_amd.raft_stereo import Coarse2FineRAFTStereoBase
+        m = make_c2f(Coarse2FineRAFTStereoBase, corr_levels=1, arithmetic=ar)
+        weightgen.fill_module_(m, "c2f.")
+        m = m.to(dev).eval()
+        f1, f2 = (x.to(dev) for x in weightgen.synthetic_frames(5, 1, 512, 960))
+        ms = timeit(lambda: m(f1, f2), 9)
+        print(f"widening [{ar}]: Coarse2Fine RAFT-Stereo 512x960, 3 x 12 iters (tiny encoder side): {ms:.1f} ms / pair = {1e3 / ms:.1f} pairs/s", flush=True)
     else:
         B = int(which[4:])
         m = make_igev(IGEVStereoBase, CostVolumeFilterNetwork, iters=32, hidden_dim=64, context_dim=64, arithmetic=ar)
@@ -70,5 +80,5 @@ if __name__ == "__main__":
     else:  # one process per (arithmetic, configuration): every measurement starts from a fresh allocator and library state
         import subprocess
         for ar in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("fp32", "bf16x3", "fp16x2")):
-            for which in ("kitti", "cre", "igev1", "igev8"):
+            for which in ("kitti", "cre", "igev1", "igev8", "c2f"):
                 subprocess.run([sys.executable, os.path.abspath(__file__), ar, which], check=False)
