@@ -856,10 +856,11 @@ static int enqueue_refine(const nnd_update_block_desc* desc, const float* packed
     const bool fused_up = !no_fuse_up && mask_upsample_supported(rate, 2 * hid, fc);
     // flow_head.conv2 folded into the fused mask / upsample launch: 1-channel flow (not CREStereo); NND_NO_FOLDED_FLOW_HEAD: two launches.
     // The second (coordinate, flow) buffer pair lives in the mask buffer, which the fused upsample never writes.
-    // Only where it pays: at most two workgroups (4x8-pixel tiles) per CU — measured at 68x120 batch 1 -2.1 ... -2.8 us per iteration, at
-    // 48x156 batch 64 -0.5 % (the fold's 134 KB of LDS leave one workgroup per CU where two fit): profiles/r04_folded_flow_head.txt.
+    // Only where it pays: at most one workgroup (4x8-pixel tile) per CU — measured at 68x120 batch 1 (255 tiles) -2.1 ... -2.8 us per
+    // iteration, at 48x156 batch 64 -0.5 %: the fold's 134 KB of LDS leave one workgroup per CU where two of the plain kernel fit, so
+    // beyond 256 tiles it would serialise what runs side by side (profiles/r04_folded_flow_head.txt).
     const bool fold_fh = fused_up && !cre && fc == 1 && mask_upsample_fold_supported(p.L[C_M2], hid) &&
-                         (long)B * cdiv(H, 4) * cdiv(W, 8) <= 512 && !switches().no_folded_flow_head;
+                         (long)B * cdiv(H, 4) * cdiv(W, 8) <= 256 && !switches().no_folded_flow_head;
     float* coords_alt = w.mask;
     float* flow_alt = w.mask + ((int64_t)B * n + 63) / 64 * 64;
     const bool fused_lk = !cre && !no_fuse_lk && flat_groups == 0;  // (the group-RAFT lookup gathers other pixels' rows: stand-alone kernel)

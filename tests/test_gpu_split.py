@@ -499,7 +499,7 @@ def test_merged_flow_branch_lookup_launch_is_bit_identical_to_two_launches(monke
 
 
 def test_folded_flow_head_is_bit_identical_to_its_own_launch(monkeypatch):
-    """Round 4 (fp16x2, grids of at most 512 tiles): flow_head.conv2 and the recurrence update run inside the fused mask / upsample launch
+    """Round 4 (fp16x2, grids of at most 256 tiles): flow_head.conv2 and the recurrence update run inside the fused mask / upsample launch
     (mask_upsample.hip: MaskUpFlowHead; four extra waves beside the mask GEMM, old and new state in two buffer pairs).  flow_head2_kernel's arithmetic: against the separate launch (NND_NO_FOLDED_FLOW_HEAD) every
     output of the loops — upsampled maps of all iterations, final low-resolution state, hidden state — must match bit for bit:
     RAFT-Stereo (ragged 13x22 map, batch 2; disparity given), IGEV (absolute coordinates, rate 4, hidden 64), the Coarse2Fine stage
