@@ -107,7 +107,9 @@ def test_corr1d_edge_cases(ops, monkeypatch):
     # wide rows: 3 and 4 w2 tiles per wave of the LDS-staged kernel, then (W > 512) the register-operand kernel; the
     # LDS-staged and the register-operand kernel must agree bit for bit (same MFMA sequence, same pooling arithmetic)
     import os
-    for (B, C, H, W) in ((1, 8, 2, 300), (1, 6, 1, 500), (1, 4, 1, 520), (2, 64, 3, 156)):
+    # (C >= 32 on these small grids: the k-split kernel — odd channel counts, channel ranges that leave the last wave short or empty, W < 32)
+    for (B, C, H, W) in ((1, 8, 2, 300), (1, 6, 1, 500), (1, 4, 1, 520), (2, 64, 3, 156), (1, 70, 5, 45), (3, 33, 2, 31), (1, 256, 4, 120),
+                         (1, 34, 1, 17)):
         f1, f2 = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
         pyr = ops.corr1d_build(f1.to(DEV), f2.to(DEV), 4)
         ref = R.corr1d_build(f1, f2, 4)
