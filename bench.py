@@ -232,6 +232,22 @@ def main():
         # the raw figure, which stays the one `achieved` / `frac` are computed from
         ev_pair_ms = eng.profile_loop_conv(rows.index(dom), pyr, 4, 4, net, inp, 8, ITERS, event_pair_only=True)
         nprod = SPLIT_PRODUCTS[args.arithmetic]  # MFMA FLOPs executed per algorithmic FLOP
+        # what the matrix pipes SUSTAIN on this box under the power limit with nothing else in flight (diagnostic, ~60 ms): context for
+        # `executed_mfma_tflops`, not the roofline's `peak` (that stays the guide's nominal figure)
+        sustained = None
+        if nprod > 1:
+            import ctypes as _C
+            from nndepth_amd._lib import lib as _nlib, check as _ncheck
+            scr = torch.zeros(16, device=dev)
+            clk = torch.zeros(512, dtype=torch.int64, device=dev)
+            tf, ghz = _C.c_float(), _C.c_float()
+            with torch.cuda.device(dev):
+                _ncheck(_nlib.nnd_profile_mfma16_peak(1 if nprod == 6 else 0, 3, 20.0, _C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                                      _C.c_void_p(scr.data_ptr()), _C.c_void_p(clk.data_ptr()), _C.byref(tf), _C.byref(ghz)),
+                        "profile_mfma16_peak")
+            sustained = {"tflops": tf.value, "shader_clock_ghz": ghz.value,
+                         "measured": "4 independent v_mfma_f32_32x32x16 chains per wave, 3 waves per SIMD on every CU, pseudo-random operands "
+                                     "in registers, 20 ms (nnd_profile_mfma16_peak); nominal 2500 TFLOP/s at 2.4 GHz"}
         # `achieved` / `peak` are ALGORITHMIC TFLOP/s: peak = what the matrix pipe could deliver of this arithmetic's fp32-equivalent
         # products = dense 16-bit MFMA peak / products per fp32 product (fp16x2: 2500 / 3 = 833; bf16x3: 2500 / 6 = 417; fp32: 157.3).
         # frac is therefore also the executed-MFMA utilisation (executed = nprod x algorithmic, against 2500).
@@ -246,6 +262,8 @@ def main():
             "flops_counted": "algorithmic (2*B*H*W*Cout*Cin*KH*KW); peak = dense 16-bit MFMA peak 2500 TFLOP/s / %d MFMA products per "
                              "fp32 product" % nprod if nprod > 1 else "algorithmic (2*B*H*W*Cout*Cin*KH*KW) against the fp32 MFMA peak",
             "executed_mfma_tflops": nprod * dom["tflops_in_loop"], "executed_mfma_peak": PEAK_BF16_MFMA_TFLOPS if nprod > 1 else PEAK_FP32_MFMA_TFLOPS,
+            "sustained_mfma_on_this_box": sustained,
+            "executed_frac_of_sustained_mfma": (nprod * dom["tflops_in_loop"] / sustained["tflops"]) if sustained else None,
             "algorithmic_frac_of_fp32_mfma_peak": dom["tflops_in_loop"] / PEAK_FP32_MFMA_TFLOPS,
             "measured": "inside the fused 32-iteration loop (hipEvents around the launch on its stream, average of iterations 2..32)",
             "launch_ms": dom["ms_in_loop"], "launch_gflop": dom["gflop"],

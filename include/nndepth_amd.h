@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NND_VERSION 103 /* 0.1.2: descriptors carry struct_size and flags; per-layer fp16x2 activation scales + calibration */
+#define NND_VERSION 104 /* 0.1.2: descriptors carry struct_size and flags; per-layer fp16x2 activation scales + calibration */
 
 /* Descriptors start with `struct_size` = sizeof(the descriptor type) of the header the caller was compiled against; every entry
  * point that takes one refuses another size (NND_ERR_INVALID), so a caller and a library of different versions cannot
@@ -504,6 +504,11 @@ int nnd_profile_loop_event_pair(const nnd_update_block_desc* desc, const float* 
 /* Diagnostic: sustained fp32-MFMA rate of this device (dependent v_mfma_f32_32x32x2 chains, no memory
  * traffic) at `waves_per_simd` resident waves; `scratch_dev` is any device buffer of >= 1 float.        */
 int nnd_profile_mfma_peak(int waves_per_simd, int iters, void* stream, float* scratch_dev, float* tflops_out);
+/* Diagnostic: the same for the 16-bit MFMA of the split arithmetics (v_mfma_f32_32x32x16_f16, or _bf16 with bf16 != 0): 4 independent
+ * chains per wave on pseudo-random operands, about `target_ms` of nothing else — the rate the chip SUSTAINS under its power limit on
+ * this box and the shader clock it settles at (nominal: 2500 TFLOP/s at 2.4 GHz).  clk_dev: device buffer of >= 512 64-bit words. */
+int nnd_profile_mfma16_peak(int bf16, int waves_per_simd, float target_ms, void* stream, float* scratch_dev,
+                            unsigned long long* clk_dev, float* tflops_out, float* ghz_out);
 int nnd_num_convs(const nnd_update_block_desc* desc);
 const char* nnd_conv_name(const nnd_update_block_desc* desc, int which);
 

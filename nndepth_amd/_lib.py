@@ -136,6 +136,7 @@ SIGNATURES = {
     "nnd_profile_loop_event_pair": (_I, [C.POINTER(UpdateBlockDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P,
                                          C.POINTER(C.c_float)]),
     "nnd_profile_mfma_peak": (_I, [_I, _I, _P, _P, C.POINTER(C.c_float)]),
+    "nnd_profile_mfma16_peak": (_I, [_I, _I, C.c_float, _P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "nnd_reload_switches": (_I, []),
     "nnd_num_convs": (_I, [C.POINTER(UpdateBlockDesc)]),
     "nnd_conv_name": (C.c_char_p, [C.POINTER(UpdateBlockDesc), _I]),

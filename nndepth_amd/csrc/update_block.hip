@@ -1190,6 +1190,85 @@ __global__ void __launch_bounds__(256) mfma_probe_kernel(float* out, int iters, 
 }
 }  // namespace nnd
 
+namespace nnd {
+// the same for the 16-bit MFMA of the split arithmetics: 4 independent v_mfma_f32_32x32x16_{f16,bf16} chains per wave on pseudo-random
+// operands (zeros would flatter the power draw), nothing else in flight — what the chip sustains under its power limit on this box
+typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+template <bool BF16>
+__global__ void __launch_bounds__(256) mfma16_probe_kernel(float* out, unsigned long long* clk, int iters, unsigned seed) {
+    unsigned s = seed ^ (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    float av[8], bv[8];
+    for (int i = 0; i < 8; ++i) {
+        s = s * 1664525u + 1013904223u;
+        av[i] = ((int)(s >> 20) & 1023) / 512.f - 1.f;
+        s = s * 1664525u + 1013904223u;
+        bv[i] = ((int)(s >> 20) & 1023) / 512.f - 1.f;
+    }
+    f32x16_ acc[4];
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (BF16) {
+        bf16x8_ a, b;
+        for (int i = 0; i < 8; ++i) a[i] = (__bf16)av[i], b[i] = (__bf16)bv[i];
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+    } else {
+        f16x8_ a, b;
+        for (int i = 0; i < 8; ++i) a[i] = (_Float16)av[i], b[i] = (_Float16)bv[i];
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 16; ++i) sum += acc[c][i];
+    if (sum == 12345.678f) out[0] = sum;  // keep the chains live without a real store
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        clk[2 * blockIdx.x] = t1 - t0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+}  // namespace nnd
+
+// scratch_dev: >= 1 float; clk_dev: >= 512 64-bit words.  One calibration launch, then launches of about `target_ms` (the clock settles
+// under load within a few milliseconds); the last one is reported: TFLOP/s and the shader clock it ran at (s_memtime / s_memrealtime).
+extern "C" int nnd_profile_mfma16_peak(int bf16, int waves_per_simd, float target_ms, void* stream, float* scratch_dev,
+                                       unsigned long long* clk_dev, float* tflops_out, float* ghz_out) {
+    NND_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 4 && target_ms > 0.f && target_ms <= 100.f && scratch_dev && clk_dev && tflops_out && ghz_out,
+                "mfma16_peak: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    NND_HIP_CHECK(hipEventCreate(&e0));
+    NND_HIP_CHECK(hipEventCreate(&e1));
+    dim3 grid(256 * waves_per_simd), block(256);
+    int iters = 2000;
+    float ms = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, s);
+        if (bf16) hipLaunchKernelGGL(nnd::mfma16_probe_kernel<true>, grid, block, 0, s, scratch_dev, clk_dev, iters, 12345u + rep);
+        else hipLaunchKernelGGL(nnd::mfma16_probe_kernel<false>, grid, block, 0, s, scratch_dev, clk_dev, iters, 12345u + rep);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep == 0) iters = (int)(iters * target_ms / (ms > 1e-3f ? ms : 1e-3f));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    unsigned long long h[512];
+    NND_HIP_CHECK(hipMemcpyAsync(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost, s));
+    NND_HIP_CHECK(hipStreamSynchronize(s));
+    double cyc = 0, rt = 0;
+    for (int i = 0; i < 256; ++i) cyc += (double)h[2 * i], rt += (double)h[2 * i + 1];
+    const double flops = 2.0 * 32 * 32 * 16 * 4.0 * iters * 4.0 * 256.0 * waves_per_simd;
+    *tflops_out = (float)(flops / (ms * 1e-3) / 1e12);
+    *ghz_out = (float)(rt > 0 ? cyc / rt * 0.1 : 0.0);  // s_memrealtime counts at 100 MHz
+    return NND_OK;
+}
+
 extern "C" int nnd_profile_mfma_peak(int waves_per_simd, int iters, void* stream, float* scratch_dev, float* tflops_out) {
     NND_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 8 && iters > 0 && scratch_dev && tflops_out, "mfma_peak: bad argument");
     hipStream_t s = (hipStream_t)stream;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/nndepth_amd.h but not exported"
     assert set(_lib.SIGNATURES) == set(syms), "ctypes table and header out of sync"
-    assert _lib.lib.nnd_version() == 103
+    assert _lib.lib.nnd_version() == 104
     assert _lib.lib.nnd_device_count() >= 0  # must not raise / abort on a CPU-only host
 
 
