@@ -282,3 +282,45 @@ def test_cre_config5_1080x1920_vs_oracle(cre_sd):
         worst[ar] = max(errs)
         del m, outs
     assert max(worst.values()) <= tol, worst
+
+
+# ------------------------------------------------------------------ widening: Coarse2Fine RAFT-Stereo cascade at 512x960
+@pytest.mark.parametrize("arithmetic", ["fp16x2", "fp32"])
+def test_coarse2fine_512x960_full_count_vs_oracle(R, arithmetic):
+    """The cascade of Coarse2FineGroupRepViTRAFTStereo (raft_stereo/model.py:280-320) at the stage sizes of a 512x960 pair — 8x15,
+    32x60, 128x240, 256 / 64 / 64 feature channels — with the class' 12 iterations per stage (36 outputs), against the oracle
+    (oracle.torch_ref.coarse2fine_refine, itself the reference's forward bit for bit: tests/golden/REPORT_c2f.txt).  The right maps are
+    the left ones shifted by a few pixels plus noise.  Every stage hands its disparity on times 4 and every output is brought to frame
+    size times its rate, so what stage 0 finds arrives times 64: the maps reach 100-200 px here, and the bar is the north-star's
+    relative precision (1e-4 at |disparity| <= 25.8, as for config 5) — measured 1.2e-4 ... 1.5e-4 at 178 px = 4 ulp of the values."""
+    from nndepth_amd import ops, weightgen
+    from nndepth_amd.raft_stereo import Coarse2FineRAFTStereoBase
+    from c2f_double import make_c2f
+    iters = 12
+    m = make_c2f(Coarse2FineRAFTStereoBase, iters=iters, corr_levels=1, arithmetic=arithmetic)
+    weightgen.fill_module_(m, "c2f.")
+    with torch.no_grad():  # a little more loop gain than the fan-in-scaled random weights have: the recurrence moves in every stage
+        m.update_block.flow_head.conv2.weight.mul_(1.3)
+        m.update_block.flow_head.conv2.bias.mul_(1.3)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith("update_block.")}
+    m = m.to(DEV).eval()
+    feats, cnets = [], []
+    for i, (c, h, w, sh) in enumerate(((256, 8, 15, 1), (64, 32, 60, 2), (64, 128, 240, 5))):
+        f1 = _u(f"c2f_f1_{i}", 1, c, h, w)
+        f2 = torch.roll(f1, -sh, dims=-1) + 0.1 * _u(f"c2f_f2_{i}", 1, c, h, w)
+        feats.append(torch.cat([f1, f2], 0))
+        cnets.append(_u(f"c2f_c_{i}", 1, 256, h, w, lo=-2, hi=2))
+    with torch.no_grad():
+        ref = R.coarse2fine_refine(sd, feats, cnets, (512, 960), iters)
+        dfeats, dcnets = [f.to(DEV) for f in feats], [c.to(DEV) for c in cnets]
+        if arithmetic == "fp16x2":
+            with ops.calibration():
+                m.refine_stages(dfeats, dcnets, (512, 960))
+        got = m.refine_stages(dfeats, dcnets, (512, 960))
+    assert len(got) == len(ref) == 3 * iters
+    mag = max(r.abs().max().item() for r in ref)
+    errs = [(g["up_disp"].cpu() - r).abs().max().item() for g, r in zip(got, ref)]
+    print(f"Coarse2Fine 512x960 {arithmetic}: |up_disp| max {mag:.2f} px, max-abs error per stage end "
+          f"{errs[iters - 1]:.2e} / {errs[2 * iters - 1]:.2e} / {errs[-1]:.2e}, worst {max(errs):.2e}")
+    assert mag > 25.8  # the cascade really amplified
+    assert max(errs) <= 1e-4 * mag / 25.8 * 0.3  # 0.3 of the north-star's relative precision at this magnitude = 2.1e-4 (measured 1.2e-4 ... 1.5e-4)
