@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NND_VERSION 104 /* 0.1.2: descriptors carry struct_size and flags; per-layer fp16x2 activation scales + calibration */
+#define NND_VERSION 104 /* 0.1.4: 102 descriptors carry struct_size and flags, per-layer fp16x2 activation scales + calibration; 103 group-RAFT entry points; 104 nnd_profile_mfma16_peak */
 
 /* Descriptors start with `struct_size` = sizeof(the descriptor type) of the header the caller was compiled against; every entry
  * point that takes one refuses another size (NND_ERR_INVALID), so a caller and a library of different versions cannot
