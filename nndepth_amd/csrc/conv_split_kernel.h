@@ -59,6 +59,16 @@ static __device__ unsigned long long g_split_stamps[4096 * 8];
 #define NND_SSTAMP(i)
 #define NND_SCLOCK(i)
 #endif
+// -DNND_DBG_STAMPS -DNND_DBG_PROLOGUE (scripts/stamps_prologue.py): slots 5 / 6 / 7 take real-time stamps INSIDE the prologue — the
+// units decoded | weight ring and first patch requested | first patch split and stored (in front of the barrier) — instead of the
+// K loop's shader-clock pair
+#if defined(NND_DBG_STAMPS) && defined(NND_DBG_PROLOGUE)
+#undef NND_SCLOCK
+#define NND_SCLOCK(i)
+#define NND_PSTAMP(i) NND_SSTAMP(i)
+#else
+#define NND_PSTAMP(i)
+#endif
 
 __host__ __device__ constexpr int split_pos_bytes(int NS) { return NS * 32 + 16; }
 __host__ __device__ constexpr int split_row_bytes(int PC, int NS) {
@@ -202,6 +212,7 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
         if constexpr (FAST) goff[i] = inimg[i] ? cho[i] * (int)SP + goff[i] : 0;  // whole offset inside the super-chunk
     }
 
+    NND_PSTAMP(5);
     f32x16 acc[P];
 #pragma unroll
     for (int pp = 0; pp < P; ++pp)
@@ -303,7 +314,9 @@ __global__ void __launch_bounds__(MAXT) conv_split_kernel(ConvArgs a) {
 #pragma unroll
     for (int g = 0; g < AD; ++g) load_a(abuf[g], a_ptr(0), g);
     load_x(0);
+    NND_PSTAMP(6);
     store_x(0);
+    NND_PSTAMP(7);
     __syncthreads();
     NND_SSTAMP(1);
     NND_SCLOCK(5);
